@@ -1,0 +1,508 @@
+"""ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement (numpy for index/integer work, torch-CPU fp32 for the floating-point network) of the
+reference algorithms on the render-then-diffuse hot path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the product
+package (``stable-renderer_amd/``) never does and fails loudly when the HIP library is missing.
+
+Parity pin: every function below is checked in ``tests/test_oracle_golden.py`` against golden vectors
+produced by running the reference itself on CPU (``oracle/gen_golden.py`` -> ``tests/golden/*.npz``).
+The rasterizer restatement lives in ``oracle/raster_ref.c`` (parity unpinned vs a GL driver, see header there).
+
+Each function cites the reference file:line it follows (paths relative to /root/reference/source).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+NON_AI_MAP_INDEX = 2048
+
+
+# ------------------------------------------------------------------------------------------------------
+# common_utils/math_utils.py:27-80
+def calc_map_mean_std(feat: torch.Tensor, eps=1e-5):
+    n, c = feat.shape[:2]
+    var = feat.reshape(n, c, -1).var(dim=2) + eps          # unbiased
+    half = var.dtype == torch.float16
+    if half:
+        var = var.float()
+    std = var.sqrt().view(n, c, 1, 1)
+    mean = feat.reshape(n, c, -1).mean(dim=2).view(n, c, 1, 1)
+    if half:
+        std = std.half()
+    return mean, std
+
+
+def adain(content: torch.Tensor, style: torch.Tensor, eps=1e-5, mode="NCHW"):
+    if mode == "NHWC":
+        content = content.permute(0, 3, 1, 2)
+        style = style.permute(0, 3, 1, 2)
+    sm, ss = calc_map_mean_std(style, eps)
+    cm, cs = calc_map_mean_std(content, eps)
+    return (content - cm) / cs * ss + sm
+
+
+# common_utils/math_utils.py:86-161
+def group_by_average(keys: np.ndarray, values: np.ndarray):
+    """keys (M,), values (M,C) -> (avg expanded back to rows (M,C) float32, unique keys sorted)."""
+    uniq, inv = np.unique(keys, return_inverse=True)
+    vals = values.astype(np.float32)
+    sums = np.zeros((len(uniq), vals.shape[1]), dtype=np.float32)
+    np.add.at(sums, inv, vals)                              # sequential fp32 accumulation, row order
+    cnt = np.zeros((len(uniq), 1), dtype=np.float32)
+    np.add.at(cnt, inv, np.float32(1.0))
+    return (sums / cnt)[inv], uniq
+
+
+# ------------------------------------------------------------------------------------------------------
+# engine/static/corrmap.py:119-126
+def idmap_masks(ids: np.ndarray) -> np.ndarray:
+    no_id = (ids[..., 2] == NON_AI_MAP_INDEX) | np.all(ids == 0, axis=-1)
+    return no_id.astype(np.float32)
+
+
+# engine/static/corrmap.py:220-280
+def vertex_screen_info(ids: np.ndarray, frame_indices=None) -> np.ndarray:
+    """(N,H,W,4) int -> (M,7) float32 rows (obj, mat, map_idx, vid, x/H, y/W, frame), (frame,y,x) order.
+    NB the reference divides x by *height* and y by *width* (corrmap.py:243, :252)."""
+    n, h, w, _ = ids.shape
+    if frame_indices is None:
+        frame_indices = list(range(n))
+    xs = (np.arange(w, dtype=np.int64).astype(np.float32) / np.float32(h)).astype(np.float32)
+    ys = (np.arange(h, dtype=np.int64).astype(np.float32) / np.float32(w)).astype(np.float32)
+    out = np.empty((n, h, w, 7), dtype=np.float32)
+    out[..., :4] = ids.astype(np.float32)
+    out[..., 4] = xs[None, None, :]
+    out[..., 5] = ys[None, :, None]
+    out[..., 6] = np.asarray(frame_indices, dtype=np.int32).astype(np.float32)[:, None, None]
+    flat = out.reshape(-1, 7)
+    flat = flat[flat[:, 2] != NON_AI_MAP_INDEX]
+    flat = flat[(flat[:, 0] != 0) | (flat[:, 1] != 0) | (flat[:, 2] != 0) | (flat[:, 3] != 0)]
+    return flat
+
+
+# common_utils/stable_render_utils/corresponder.py:298-376
+def overlap_step(x: torch.Tensor, ids: np.ndarray, ratio: float) -> torch.Tensor:
+    """One OverlapCorresponder.step_finished on latents x (N,4,h,w) fp32 (caller checks the timestep gate).
+    Gather latent cell of every id pixel, mean over rows sharing vertexID, blend, scatter back (duplicate
+    targets: last row wins, as index_put on CPU), then AdaIN(content=x, style=blended)."""
+    vsi = vertex_screen_info(ids)
+    n, c, h, w = x.shape
+    sx = (vsi[:, 4] * np.float32(w)).astype(np.int32)       # fp32 multiply, truncate
+    sy = (vsi[:, 5] * np.float32(h)).astype(np.int32)
+    fr = vsi[:, 6].astype(np.int32)
+    xc = x.float().numpy().copy()
+    v = xc[fr, :, sy, sx]                                   # (M, C)
+    avg, _ = group_by_average(vsi[:, 3], v)
+    blended = (np.float32(1.0 - ratio) * v + np.float32(ratio) * avg).astype(np.float32)
+    # sequential scatter == last writer wins
+    xc[fr, :, sy, sx] = blended
+    return adain(x.clone().float(), torch.from_numpy(xc))
+
+
+# common_utils/stable_render_utils/corresponder.py:188-220
+def pre_atten_inject(n_ctx: torch.Tensor, idx):
+    kv = torch.cat([n_ctx[int(i)] for i in idx], dim=0).unsqueeze(0).expand(n_ctx.shape[0], -1, -1)
+    return n_ctx, kv, kv
+
+
+# engine/managers/renderManager.py:926-936
+def noise_pool(noise_f16: torch.Tensor, alpha_f16: torch.Tensor, bg_f32: torch.Tensor):
+    """noise (1,H,W,4) fp16, alpha (1,H,W) fp16 (colour alpha), bg (1,H,W,4) fp32 -> pooled (H/8,W/8,4) fp32,
+    latent noise (1,4,H/8,W/8).  'view(-1,8,8,4).mean((1,2))' = mean of 64 consecutive pixels of a row."""
+    H, W = noise_f16.shape[1:3]
+    mask = (1.0 - alpha_f16).unsqueeze(-1).expand_as(noise_f16)      # fp16
+    n = noise_f16 * (1.0 - mask) + bg_f32 * mask                       # fp16*fp16 -> fp16, + fp32 -> fp32
+    pooled = n.reshape(-1, 64, 4).mean(dim=1).view(H // 8, W // 8, 4)
+    out = adain(pooled.unsqueeze(0), noise_f16, mode="NHWC").contiguous()
+    return pooled, out
+
+
+# ------------------------------------------------------------------------------------------------------
+# engine/static/corrmap.py:578-736
+def corrmap_update(values: np.ndarray, writtens: np.ndarray, frames: np.ndarray, ids: np.ndarray,
+                   sprite=None, material=None, mode="first_avg", masks=None, inverse_masks=False,
+                   ignore_obj_mat_id=False, channel_count=4):
+    """In-place on values (k*k, V, C) fp16 / writtens (k*k, V) bool.  frames (N,H,W,3|4) float, ids (N,H,W,4).
+    Reproduces the reference including its double gather of the colour rows (corrmap.py:703,710): after the
+    mask compaction the colour rows are re-indexed with ORIGINAL pixel indices -> IndexError / wrong rows
+    when the mask is partial and the sprite/material filter runs."""
+    if ids.ndim != 4:
+        raise ValueError("id maps must be (N,H,W,4): the reference never returns for a 3-D id map "
+                         "(corrmap.py:629 appends to the list it iterates)")
+    if frames.ndim == 3:
+        frames = frames[None]
+    if len(frames) != len(ids):
+        raise ValueError("The length of color_frames and id_maps should be the same")
+    for f in range(len(frames)):
+        col = frames[f].astype(np.float32)
+        if channel_count < col.shape[-1]:
+            col = col[..., :channel_count]
+        elif channel_count == 4 and col.shape[-1] == 3:
+            col = np.concatenate([col, np.ones_like(col[..., :1])], -1)
+        idm = ids[f].reshape(-1, 4).astype(np.int64)
+        npx = idm.shape[0]
+        row = np.arange(npx, dtype=np.int64)                # original pixel index of each surviving id row
+        col = col.reshape(npx, -1)
+        if masks is not None:
+            m = masks[f].reshape(-1).astype(np.float32)
+            if inverse_masks:
+                m = 1 - m
+            keep = m > 0
+            row, idm = row[keep], idm[keep]
+            col = col[row]
+        if not ignore_obj_mat_id:
+            if sprite is not None:
+                k2 = idm[:, 0] == sprite
+                row, idm = row[k2], idm[k2]
+            if material is not None:
+                k3 = idm[:, 1] == material
+                row, idm = row[k3], idm[k3]
+            col = col[row]                                  # <- quirk: indexes the (possibly compacted) rows
+        mi, vid = idm[:, 2], idm[:, 3]
+        if mode in ("first", "first_avg"):
+            w = writtens[mi, vid]
+            mi, vid, col = mi[~w], vid[~w], col[~w]
+        values[mi, vid] = col.astype(np.float16)            # duplicates: last row wins
+        writtens[mi, vid] = True
+
+
+# ------------------------------------------------------------------------------------------------------
+# comfy/model_sampling.py:75-150 (ModelSamplingDiscrete, linear-in-sqrt beta schedule)
+def sigma_table(linear_start=0.00085, linear_end=0.012, timesteps=1000):
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    return (((1 - ac) / ac) ** 0.5).float()
+
+
+class ModelSampling:
+    def __init__(self):
+        self.sigmas = sigma_table()
+        self.log_sigmas = self.sigmas.log()
+        self.sigma_min = self.sigmas[0]
+        self.sigma_max = self.sigmas[-1]
+
+    def timestep(self, sigma):
+        sigma = torch.as_tensor(sigma, dtype=torch.float32)
+        d = sigma.log().reshape(1, -1) - self.log_sigmas[:, None]
+        return d.abs().argmin(dim=0).view(sigma.shape)
+
+    def sigma(self, t):
+        t = torch.clamp(torch.as_tensor(t).float(), min=0, max=len(self.sigmas) - 1)
+        lo, hi, w = t.floor().long(), t.ceil().long(), t.frac()
+        return ((1 - w) * self.log_sigmas[lo] + w * self.log_sigmas[hi]).exp()
+
+
+# comfy/samplers.py:415-451, 937-951 ; comfy/k_diffusion/sampling.py:17-36
+def scheduler_sigmas(ms: ModelSampling, name: str, steps: int) -> torch.Tensor:
+    if name in ("normal", "sgm_uniform"):
+        start, end = ms.timestep(ms.sigma_max), ms.timestep(ms.sigma_min)
+        ts = torch.linspace(start, end, steps + 1)[:-1] if name == "sgm_uniform" else torch.linspace(start, end, steps)
+        return torch.FloatTensor([float(ms.sigma(t)) for t in ts] + [0.0])
+    if name == "simple":
+        ss = len(ms.sigmas) / steps
+        return torch.FloatTensor([float(ms.sigmas[-(1 + int(i * ss))]) for i in range(steps)] + [0.0])
+    if name == "ddim_uniform":
+        ss = max(len(ms.sigmas) // steps, 1)
+        sig = []
+        i = 1
+        while i < len(ms.sigmas):
+            sig.append(float(ms.sigmas[i]))
+            i += ss
+        return torch.FloatTensor(sig[::-1] + [0.0])
+    if name == "karras":
+        rho = 7.0
+        ramp = torch.linspace(0, 1, steps)
+        a, b = float(ms.sigma_min) ** (1 / rho), float(ms.sigma_max) ** (1 / rho)
+        s = (b + ramp * (a - b)) ** rho
+        return torch.cat([s, s.new_zeros([1])])
+    if name == "exponential":
+        s = torch.linspace(math.log(float(ms.sigma_max)), math.log(float(ms.sigma_min)), steps).exp()
+        return torch.cat([s, s.new_zeros([1])])
+    raise ValueError(name)
+
+
+# comfy/samplers.py:979-1003 (KSampler.calculate_sigmas / set_steps; discard-penultimate samplers omitted)
+def ksampler_sigmas(ms: ModelSampling, scheduler: str, steps: int, denoise=None):
+    if denoise is None or denoise > 0.9999:
+        sig = scheduler_sigmas(ms, scheduler, steps)
+        ts = [int(ms.timestep(s)) for s in sig]
+        return sig, ts
+    new_steps = int(steps / denoise)
+    sig = scheduler_sigmas(ms, scheduler, new_steps)
+    ts = [int(ms.timestep(s)) for s in sig]           # NOT re-sliced (samplers.py:1000-1003 quirk)
+    return sig[-(steps + 1):], ts
+
+
+# comfy/model_sampling.py:7-29
+def eps_input(x, sigma):
+    return x / (sigma.view(-1, 1, 1, 1) ** 2 + 1.0) ** 0.5
+
+
+def eps_denoised(x, out, sigma):
+    return x - out * sigma.view(-1, 1, 1, 1)
+
+
+# comfy/k_diffusion/sampling.py:129-149 / 749-793
+def sample_loop(denoise_fn, x, sigmas, sampler="euler", callback=None):
+    """denoise_fn(x, sigma_vec) -> denoised.  sampler in euler|ddim|ddpm|lcm (ddim == euler w/o mask).
+    callback(i, x, denoised) fires after the model call, before the update (may mutate x in place)."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        den = denoise_fn(x, sigmas[i] * s_in)
+        if sampler in ("euler", "ddim"):
+            d = (x - den) / sigmas[i]           # sample_euler computes d BEFORE the callbacks mutate x (:140-144)
+        if callback is not None:
+            callback(i, x, den)
+        if sampler in ("euler", "ddim"):
+            x = x + d * (sigmas[i + 1] - sigmas[i])
+        elif sampler == "ddpm":
+            sg, sp = sigmas[i], sigmas[i + 1]
+            xs = x / torch.sqrt(1.0 + sg ** 2.0)
+            noise = (x - den) / sg
+            ac, acp = 1 / (sg * sg + 1), 1 / (sp * sp + 1)
+            al = ac / acp
+            mu = (1.0 / al).sqrt() * (xs - (1 - al) * noise / (1 - ac).sqrt())
+            if sp > 0:
+                mu = mu + ((1 - al) * (1. - acp) / (1. - ac)).sqrt() * torch.randn_like(x)
+            x = mu
+            if sp != 0:
+                x = x * torch.sqrt(1.0 + sp ** 2.0)
+        elif sampler == "lcm":
+            x = den
+            if sigmas[i + 1] > 0:
+                x = x + sigmas[i + 1] * torch.randn_like(x)
+        else:
+            raise ValueError(sampler)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------------
+# UNet (comfy/ldm/modules/diffusionmodules/openaimodel.py, comfy/ldm/modules/attention.py), functional,
+# driven by the checkpoint-format state dict.
+SD15_CFG = dict(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=[2, 2, 2, 2],
+                channel_mult=[1, 2, 4, 4], transformer_depth=[1, 1, 1, 1, 1, 1, 0, 0], transformer_depth_middle=1,
+                transformer_depth_output=[1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0], context_dim=768, num_heads=8)
+
+
+def timestep_embedding(t, dim, max_period=10000):          # util.py:241-261
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def _gn(x, sd, p, eps, groups=32):
+    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def _attention(q, k, v, heads):                             # attention.py:92-140 (attention_basic, fp32)
+    b, tq, c = q.shape
+    d = c // heads
+    q = q.view(b, tq, heads, d).transpose(1, 2)
+    k = k.view(k.shape[0], -1, heads, d).transpose(1, 2)
+    v = v.view(v.shape[0], -1, heads, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
+    o = torch.matmul(s.softmax(dim=-1), v)
+    return o.transpose(1, 2).reshape(b, tq, c)
+
+
+def _resblock(sd, p, x, emb):                               # openaimodel.py:253-281
+    h = F.conv2d(F.silu(_gn(x, sd, p + ".in_layers.0", 1e-5)), sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"], padding=1)
+    e = F.linear(F.silu(emb), sd[p + ".emb_layers.1.weight"], sd[p + ".emb_layers.1.bias"])
+    h = h + e[:, :, None, None]
+    h = F.conv2d(F.silu(_gn(h, sd, p + ".out_layers.0", 1e-5)), sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
+    if (p + ".skip_connection.weight") in sd:
+        x = F.conv2d(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
+    return x + h
+
+
+def _tblock(sd, p, x, ctx, heads, inject_idx):              # attention.py:495-654
+    n = F.layer_norm(x, x.shape[-1:], sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])
+    kv = n
+    if inject_idx is not None:
+        _, kv, _ = pre_atten_inject(n, inject_idx)
+    q = F.linear(n, sd[p + ".attn1.to_q.weight"])
+    k = F.linear(kv, sd[p + ".attn1.to_k.weight"])
+    v = F.linear(kv, sd[p + ".attn1.to_v.weight"])
+    a = _attention(q, k, v, heads)
+    x = x + F.linear(a, sd[p + ".attn1.to_out.0.weight"], sd[p + ".attn1.to_out.0.bias"])
+    n = F.layer_norm(x, x.shape[-1:], sd[p + ".norm2.weight"], sd[p + ".norm2.bias"])
+    q = F.linear(n, sd[p + ".attn2.to_q.weight"])
+    k = F.linear(ctx, sd[p + ".attn2.to_k.weight"])
+    v = F.linear(ctx, sd[p + ".attn2.to_v.weight"])
+    a = _attention(q, k, v, heads)
+    x = x + F.linear(a, sd[p + ".attn2.to_out.0.weight"], sd[p + ".attn2.to_out.0.bias"])
+    n = F.layer_norm(x, x.shape[-1:], sd[p + ".norm3.weight"], sd[p + ".norm3.bias"])
+    g = F.linear(n, sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"])
+    a, gate = g.chunk(2, dim=-1)
+    return x + F.linear(a * F.gelu(gate), sd[p + ".ff.net.2.weight"], sd[p + ".ff.net.2.bias"])
+
+
+def _stransformer(sd, p, x, ctx, heads, depth, inject_idx):  # attention.py:699-726 (conv proj, SD1.x)
+    b, c, h, w = x.shape
+    x_in = x
+    x = _gn(x, sd, p + ".norm", 1e-6)
+    x = F.conv2d(x, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    x = x.flatten(2).transpose(1, 2)
+    for i in range(depth):
+        x = _tblock(sd, f"{p}.transformer_blocks.{i}", x, ctx, heads, inject_idx)
+    x = x.transpose(1, 2).reshape(b, c, h, w)
+    x = F.conv2d(x, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+    return x + x_in
+
+
+def unet_forward(sd, cfg, x, t, ctx, inject_idx=None, control=None):
+    """openaimodel.py:841-946.  sd: state dict with 'input_blocks.*' style keys (no prefix), fp32."""
+    mc, heads = cfg["model_channels"], cfg["num_heads"]
+    emb = timestep_embedding(t, mc)
+    emb = F.linear(F.silu(F.linear(emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])),
+                   sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    hs = []
+    h = F.conv2d(x, sd["input_blocks.0.0.weight"], sd["input_blocks.0.0.bias"], padding=1)
+    hs.append(h)
+    td = list(cfg["transformer_depth"])
+    bi = 1
+    nlev = len(cfg["channel_mult"])
+    for lev in range(nlev):
+        for _ in range(cfg["num_res_blocks"][lev]):
+            h = _resblock(sd, f"input_blocks.{bi}.0", h, emb)
+            depth = td.pop(0)
+            if depth > 0:
+                h = _stransformer(sd, f"input_blocks.{bi}.1", h, ctx, heads, depth, inject_idx)
+            hs.append(h)
+            bi += 1
+        if lev != nlev - 1:
+            h = F.conv2d(h, sd[f"input_blocks.{bi}.0.op.weight"], sd[f"input_blocks.{bi}.0.op.bias"], stride=2, padding=1)
+            hs.append(h)
+            bi += 1
+    h = _resblock(sd, "middle_block.0", h, emb)
+    h = _stransformer(sd, "middle_block.1", h, ctx, heads, cfg["transformer_depth_middle"], inject_idx)
+    h = _resblock(sd, "middle_block.2", h, emb)
+    if control is not None and control.get("middle"):
+        h = h + control["middle"].pop()
+    tdo = list(cfg["transformer_depth_output"])
+    bi = 0
+    for lev in reversed(range(nlev)):
+        for i in range(cfg["num_res_blocks"][lev] + 1):
+            hsp = hs.pop()
+            if control is not None and control.get("output"):
+                c_ = control["output"].pop()
+                if c_ is not None:
+                    hsp = hsp + c_
+            h = torch.cat([h, hsp], dim=1)
+            h = _resblock(sd, f"output_blocks.{bi}.0", h, emb)
+            depth = tdo.pop()                               # openaimodel.py pops from the END
+            j = 1
+            if depth > 0:
+                h = _stransformer(sd, f"output_blocks.{bi}.1", h, ctx, heads, depth, inject_idx)
+                j = 2
+            if lev > 0 and i == cfg["num_res_blocks"][lev]:
+                h = F.interpolate(h, scale_factor=2, mode="nearest")
+                h = F.conv2d(h, sd[f"output_blocks.{bi}.{j}.conv.weight"], sd[f"output_blocks.{bi}.{j}.conv.bias"], padding=1)
+            bi += 1
+    h = F.silu(_gn(h, sd, "out.0", 1e-5))
+    return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
+
+
+# ------------------------------------------------------------------------------------------------------
+# VAE decoder (comfy/ldm/modules/diffusionmodules/model.py:541-650; ddconfig comfy/sd.py:259)
+def _vae_res(sd, p, x):
+    h = F.conv2d(F.silu(_gn(x, sd, p + ".norm1", 1e-6)), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
+    h = F.conv2d(F.silu(_gn(h, sd, p + ".norm2", 1e-6)), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    if (p + ".nin_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[p + ".nin_shortcut.weight"], sd[p + ".nin_shortcut.bias"])
+    return x + h
+
+
+def _vae_attn(sd, p, x):
+    b, c, h, w = x.shape
+    n = _gn(x, sd, p + ".norm", 1e-6)
+    q = F.conv2d(n, sd[p + ".q.weight"], sd[p + ".q.bias"]).flatten(2).transpose(1, 2)
+    k = F.conv2d(n, sd[p + ".k.weight"], sd[p + ".k.bias"]).flatten(2).transpose(1, 2)
+    v = F.conv2d(n, sd[p + ".v.weight"], sd[p + ".v.bias"]).flatten(2).transpose(1, 2)
+    o = _attention(q, k, v, 1).transpose(1, 2).reshape(b, c, h, w)
+    return x + F.conv2d(o, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+
+
+def vae_decoder(sd, z, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    h = F.conv2d(z, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    h = _vae_res(sd, "mid.block_1", h)
+    h = _vae_attn(sd, "mid.attn_1", h)
+    h = _vae_res(sd, "mid.block_2", h)
+    for lev in reversed(range(len(ch_mult))):
+        for i in range(num_res_blocks + 1):
+            h = _vae_res(sd, f"up.{lev}.block.{i}", h)
+        if lev != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = F.conv2d(h, sd[f"up.{lev}.upsample.conv.weight"], sd[f"up.{lev}.upsample.conv.bias"], padding=1)
+    h = F.silu(_gn(h, sd, "norm_out", 1e-6))
+    return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
+def vae_decode_image(sd, z, **kw):                          # comfy/sd.py:329-346 (Decoder part)
+    return torch.clamp((vae_decoder(sd, z, **kw) + 1.0) / 2.0, min=0.0, max=1.0).movedim(1, -1)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Whole sampling stack: custom_ksampler -> comfy.sample.sample -> KSampler -> sampling_function ->
+# calc_cond_uncond_batch -> BaseModel.apply_model (nodes.py:1438, samplers.py:176-358, model_base.py:93-127)
+LATENT_SCALE = 0.18215                                     # comfy/latent_formats.py SD15
+
+
+def sample_frames(sd, cfg, noise, pos, neg, ids, steps, cfg_scale, sampler, scheduler, denoise=1.0,
+                  overlap=None, latent=None, seed=None):
+    """noise (N,4,h,w); pos/neg (1,77,C); ids (N,H,W,4) or None; overlap = dict(ratio, stop, n_rand) or None.
+    RNG draw order replicates the reference (global torch RNG): custom_ksampler's seed randint, then
+    pre_atten_inject's randint on the first attention block, then the sampler's per-step randn_like."""
+    ms = ModelSampling()
+    sig, timesteps = ksampler_sigmas(ms, scheduler, steps, denoise)
+    n = noise.shape[0]
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 32, (1,)).item())  # custom_ksampler(seed=None) (nodes.py:1455)
+    if latent is None:
+        latent = torch.zeros_like(noise)
+    latent = latent * LATENT_SCALE                          # process_latent_in (samplers.py:888, latent_formats.py)
+    if sampler == "ddim":
+        # "ddim" = euler + inpaint_options{"random"} (samplers.py:821-822): SAMPLER_METHOD.sample RESEEDS the
+        # global RNG with seed+1 and draws one noise tensor from it (samplers.py:766-768) even with no mask.
+        g = torch.manual_seed(seed + 1)
+        torch.randn(noise.shape, generator=g, device="cpu")
+    # noise_scaling (model_sampling.py:21-29); max_denoise when sigma[0] ~ sigma_max (samplers.py:745-751)
+    max_denoise = math.isclose(float(ms.sigma_max), float(sig[0]), rel_tol=1e-05) or float(sig[0]) > float(ms.sigma_max)
+    x = noise * (torch.sqrt(1.0 + sig[0] ** 2.0) if max_denoise else sig[0]) + latent
+    state = {"idx": None}
+    use_cfg = not math.isclose(cfg_scale, 1.0)
+
+    def denoise_fn(xx, sigma):
+        # batch order: uncond chunk first, then cond (samplers.py:230-262)
+        if use_cfg:
+            xin = torch.cat([xx, xx])
+            s2 = torch.cat([sigma, sigma])
+            c = torch.cat([neg.expand(n, -1, -1), pos.expand(n, -1, -1)])
+        else:
+            xin, s2, c = xx, sigma, pos.expand(n, -1, -1)
+        inj = None
+        if overlap is not None and overlap.get("n_rand", 1) >= 0:
+            if state["idx"] is None:
+                state["idx"] = torch.randint(1, xin.shape[0], (overlap.get("n_rand", 1),))
+            inj = state["idx"]
+        t = ms.timestep(s2).float()
+        out = unet_forward(sd, cfg, eps_input(xin, s2), t, c, inject_idx=inj)
+        den = eps_denoised(xin, out, s2)
+        if use_cfg:
+            u, cnd = den[:n], den[n:]
+            return u + (cnd - u) * cfg_scale
+        return den
+
+    def cb(i, xx, den):
+        if overlap is None or ids is None:
+            return
+        if timesteps[i] < overlap["stop"]:
+            return
+        xx.copy_(overlap_step(xx, ids, overlap["ratio"]))
+
+    out = sample_loop(denoise_fn, x, sig, sampler, cb)
+    return out / LATENT_SCALE, state["idx"]                 # process_latent_out (samplers.py:933)
