@@ -1,0 +1,232 @@
+/* sr_hip.h — C ABI of libsr_hip.so: the MI355X (gfx950) hot path of the render-then-diffuse frame loop.
+ *
+ * The reference (92MING/Stable-Renderer) has no FFI for this path: everything is Python + GLSL + torch ops
+ * (SURVEY.md §8b).  These entry points are what a binding *beneath* the reference's Python operators calls;
+ * each one cites the reference code it replaces (paths relative to <reference>/source).  INTEGRATION.md
+ * shows the ctypes stubs a maintainer of the reference would add.
+ *
+ * Conventions: extern "C"; every pointer is a caller-owned DEVICE pointer unless named host_*; sizes are
+ * plain ints; `stream` is a hipStream_t passed as void* (NULL = default stream); return 0 on success or a
+ * negative sr_status.  No hidden global state, no allocation, no host<->device sync inside any call unless
+ * the comment says so (graph-capture safe).  Activations are NHWC ("pixels x channels"), dtype tag SR_F16 or
+ * SR_F32 selects the arithmetic path (fp16 MFMA with fp32 accumulate / exact fp32 MFMA).
+ */
+#ifndef SR_HIP_H
+#define SR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SR_OK = 0,
+  SR_ERR_INVALID = -1,     /* bad argument / unsupported shape (message via sr_last_error) */
+  SR_ERR_LAUNCH = -2,      /* HIP launch/runtime error */
+  SR_ERR_UNSUPPORTED = -3
+} sr_status;
+
+typedef enum { SR_F16 = 0, SR_F32 = 1 } sr_dtype;
+
+const char* sr_last_error(void);          /* thread-local text of the last failure */
+int sr_version(void);
+int sr_device_sync(void);                  /* hipDeviceSynchronize (tests only) */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer on MFMA.
+ * Replaces torch conv2d / Linear inside ResBlock._forward (comfyUI/comfy/ldm/modules/diffusionmodules/
+ * openaimodel.py:253-281), Upsample/Downsample (:82-148), SpatialTransformer proj_in/out and the q/k/v/out/
+ * FF Linear layers of BasicTransformerBlock (comfy/ldm/modules/attention.py:495-726), and the VAE decoder
+ * convs (comfy/ldm/modules/diffusionmodules/model.py:541-650).
+ * out[m, n] = act( scale * sum_k A[m,k] * Wt[n,k] + bias[n] + rowvec[b(m), n] ) + residual[m, n]
+ *   m = (b, oy, ox) output pixel, k = (ky, kx, c) with c running over the channel concat [a | a2].
+ */
+typedef struct {
+  const void* a;          /* [B, H, W, C1] activations (dtype)                                        */
+  const void* a2;         /* optional [B, H, W, C2] second source (decoder skip concat) or NULL        */
+  const void* w;          /* packed weights [Npad, KH*KH*(C1+C2)] dtype, K contiguous, Npad%128==0     */
+  const float* bias;      /* [N] fp32 or NULL                                                          */
+  const float* rowvec;    /* [B, N] fp32 added per batch entry (time embedding) or NULL                */
+  const void* residual;   /* [M, N] dtype or NULL (ignored when transpose_out)                         */
+  void* out;              /* [M, N] (or [B, N, ldt] when transpose_out) dtype, fp32 when out_f32       */
+  const void* zero_page;  /* >= 16 bytes of zeros (source for padding taps / rows >= M)                 */
+  int32_t B, H, W;        /* input batch and spatial size                                              */
+  int32_t C1, C2;         /* channels of a / a2 (multiples of 64 for fp16, 32 for fp32)                */
+  int32_t N;              /* valid output channels (N of the GEMM; for GEGLU the 2*inner interleaved)  */
+  int32_t KH;             /* 1 or 3 (square kernel, pad = KH/2)                                        */
+  int32_t stride;         /* 1 or 2                                                                    */
+  int32_t upsample;       /* 1: nearest x2 upsample fused in front of the conv (Upsample, :82-119)     */
+  int32_t act;            /* 0 none, 1 SiLU, 2 GEGLU (pairs (value,gate) interleaved along n), 3 GELU  */
+  int32_t transpose_out;  /* 1: write out[b][n][t] (t = pixel in batch, row stride ldt) — V^T for attn */
+  int32_t ldt;            /* row stride of the transposed output (>= pixels per batch)                 */
+  int32_t out_f32;        /* 1: store fp32 regardless of dtype                                         */
+  int32_t dtype;          /* sr_dtype                                                                  */
+  float scale;            /* multiplies the accumulator (1.0 normally)                                 */
+} sr_igemm_args;
+int sr_igemm(const sr_igemm_args* args, void* stream);
+
+/* GroupNorm(32 groups) [+SiLU] over NHWC, optional channel concat of two sources (th.cat([h, hsp]) in
+ * UNetModel.forward, openaimodel.py:921).  Replaces GroupNorm32 + SiLU in ResBlock.in_layers/out_layers,
+ * SpatialTransformer.norm (eps 1e-6), VAE Normalize.  `partials` scratch: B*chunks*64 floats (see
+ * sr_groupnorm_scratch_floats). */
+typedef struct {
+  const void* x; const void* x2;      /* [B, HW, C1], [B, HW, C2] or NULL */
+  const float* gamma; const float* beta;  /* [C1+C2] fp32 */
+  void* y;                             /* [B, HW, C1+C2] dtype */
+  float* partials;                     /* scratch */
+  int32_t B, HW, C1, C2, groups, silu, dtype;
+  float eps;
+} sr_groupnorm_args;
+int sr_groupnorm(const sr_groupnorm_args* args, void* stream);
+int64_t sr_groupnorm_scratch_floats(int32_t B, int32_t HW);
+
+/* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3, attention.py:521,613,648). rows x C. */
+int sr_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t rows, int32_t C,
+                 float eps, int32_t dtype, void* stream);
+
+/* Fused softmax(Q K^T / sqrt(d)) V (optimized_attention, attention.py:92-387), fp32 softmax statistics.
+ *  q  [B, Tq, heads*d]   k [Bk, Tk, heads*d]   vt [Bk, heads, d, ldt] (V transposed, written by sr_igemm
+ *  transpose_out)   o [B, Tq, heads*d].  Bk == B, or Bk == 1: every batch entry attends to the same K/V
+ *  (OverlapCorresponder.pre_atten_inject, common_utils/stable_render_utils/corresponder.py:188-220). */
+typedef struct {
+  const void* q; const void* k; const void* vt; void* o;
+  int32_t B, Bk, Tq, Tk, heads, d, ldt, dtype;
+  int32_t q_stride, k_stride;   /* row strides in elements (heads*d when packed) */
+  float scale;                  /* d^-0.5 */
+} sr_attention_args;
+int sr_attention(const sr_attention_args* args, void* stream);
+
+/* small element-wise pieces of UNetModel.forward / BaseModel.apply_model */
+int sr_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t HW, int32_t Cpad, float scale_mul,
+                    const float* per_batch_scale, int32_t dtype, void* stream);   /* y[b,p,c] = x[b,c,p]*s */
+int sr_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t HW, int32_t ldc, int32_t dtype,
+                    void* stream);
+int sr_timestep_embedding(const float* t, void* y, int32_t B, int32_t dim, int32_t dtype, void* stream);
+                                                    /* util.py:241-261: cat(cos, sin)(t * 10000^(-i/half)) */
+int sr_silu(const void* x, void* y, int64_t n, int32_t dtype, void* stream);
+int sr_cast(const void* x, int32_t src_dtype, void* y, int32_t dst_dtype, int64_t n, void* stream);
+int sr_softmax_rows(void* x, int32_t rows, int32_t cols, int32_t dtype, void* stream);   /* in place; VAE mid attention */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Launch plan: a flat array of ops executed back-to-back on one stream by native code (the Python host
+ * builds it once per (model, batch, resolution); no Python in the per-step path).  */
+typedef enum {
+  SR_OP_IGEMM = 1, SR_OP_GROUPNORM = 2, SR_OP_LAYERNORM = 3, SR_OP_ATTENTION = 4, SR_OP_NCHW_TO_NHWC = 5,
+  SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9
+} sr_op_kind;
+typedef struct {
+  int32_t kind; int32_t pad_;
+  union {
+    sr_igemm_args igemm;
+    sr_groupnorm_args gn;
+    sr_attention_args attn;
+    struct { const void* x; const float* gamma; const float* beta; void* y; int32_t rows, C, dtype; float eps; } ln;
+    struct { const void* x; void* y; const float* per_batch_scale; int32_t B, C, HW, Cpad, dtype, ldc; float scale; } cvt;
+    struct { const float* t; void* y; int32_t B, dim, dtype; } temb;
+    struct { const void* x; void* y; int64_t n; int32_t dtype; int32_t rows, cols; } ew;
+  } u;
+} sr_op;
+int sr_plan_run(const sr_op* host_ops, int32_t n_ops, void* stream);
+/* Capture the plan into a hipGraph on `stream` (must be a non-default stream); *graph_exec receives an opaque
+ * handle for sr_graph_launch / sr_graph_destroy. */
+int sr_plan_capture(const sr_op* host_ops, int32_t n_ops, void* stream, void** graph_exec);
+int sr_graph_launch(void* graph_exec, void* stream);
+int sr_graph_destroy(void* graph_exec);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Sampler arithmetic (comfy/model_sampling.py:7-29 EPS; comfy/samplers.py:323-358 CFG;
+ * comfy/k_diffusion/sampling.py:129-149 euler, :749-776 ddpm, :779-793 lcm).  All fp32, x is (N,4,h,w). */
+/* xin[0:N] = xin[N:2N] = x / sqrt(sigma^2+1)  (uncond chunk first, then cond; `copies` = 1 or 2) */
+int sr_eps_scale_input(const float* x, float* xin, int64_t n_per_copy, int32_t copies, float sigma, void* stream);
+/* denoised = x - eps*sigma per chunk; CFG: u + (c-u)*cfg (copies==2, eps = [uncond | cond]);
+ * d = (x - denoised)/sigma (euler derivative, computed BEFORE callbacks as the reference does) */
+int sr_cfg_denoise(const float* x, const float* eps, float* denoised, float* d, int64_t n, int32_t copies,
+                   float sigma, float cfg, void* stream);
+int sr_euler_step(float* x, const float* d, int64_t n, float dt, void* stream);           /* x += d*dt */
+/* DDPMSampler_step + rescale; noise = host-drawn randn (may be NULL when sigma_next == 0) */
+int sr_ddpm_step(float* x, const float* denoised, const float* noise, int64_t n, float sigma, float sigma_next,
+                 void* stream);
+int sr_lcm_step(float* x, const float* denoised, const float* noise, int64_t n, float sigma_next, void* stream);
+int sr_axpby(float* y, const float* x, int64_t n, float a, float b, void* stream);         /* y = a*x + b*y */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Stable-rendering kernels */
+/* IDMap masks (engine/static/corrmap.py:119-126): mask = (map_index==2048) | all-zero, as fp32 0/1. */
+int sr_idmap_masks(const int32_t* ids, float* masks, int64_t n_pixels, void* stream);
+
+/* Build the per-call overlap structure from id maps (replaces IDMap.create_vertex_screen_info,
+ * corrmap.py:220-280 + the per-step unique() of tensor_group_by_then_average, math_utils.py:86-161).
+ * For every valid pixel (frame f, y, x): latent cell = (f, int(fp32(y/W)*lh), int(fp32(x/H)*lw)).
+ *   cell_vid[cell]  = vertexID of the LAST valid pixel (f,y,x order) mapping to the cell, -1 if none
+ *   pix_cell[pixel] = cell index or -1, pix_vid[pixel] = vertexID (valid pixels only)
+ * vid_capacity = 1 + max vertexID the dense per-vertex tables must hold (returned through *max_vid, device).
+ * Two-pass, no atomics on the winner: deterministic = sequential "last writer wins". */
+int sr_overlap_build(const int32_t* ids, int32_t N, int32_t H, int32_t W, int32_t lh, int32_t lw,
+                     int32_t* pix_cell, int32_t* cell_vid, int32_t* max_vid, void* stream);
+/* One OverlapCorresponder.step_finished (corresponder.py:298-376) on x (N,C,lh,lw) fp32, in place:
+ * per-vertex mean of the gathered cells (each id pixel counts once), blend (1-r)*v + r*mean into the
+ * winning row's cell, then AdaIN(content = x, style = blended) per (n,c) (math_utils.py:55-80).
+ * vsum: scratch (vid_capacity*(C+1)) floats, zeroed by the call.  stats: scratch N*C*4 floats. */
+int sr_overlap_step(float* x, const int32_t* ids, const int32_t* pix_cell, const int32_t* cell_vid,
+                    int32_t N, int32_t C, int32_t H, int32_t W, int32_t lh, int32_t lw, int32_t vid_capacity,
+                    float ratio, float* vsum, float* blended, float* stats, void* stream);
+
+/* adaptive_instance_normalization NCHW fp32 (math_utils.py:27-80): out = (c-mean_c)/std_c*std_s+mean_s,
+ * std = sqrt(unbiased var + eps).  content (N,C,HWc), style (N,C,HWs) with element strides so NHWC inputs
+ * work too (chan stride / pixel stride).  stats scratch N*C*4 floats. */
+int sr_adain(const float* content, int64_t c_ps, int64_t c_cs, int64_t c_ns, int32_t HWc,
+             const void* style, int32_t style_dtype, int64_t s_ps, int64_t s_cs, int64_t s_ns, int32_t HWs,
+             float* out, int32_t N, int32_t C, float eps, float* stats, void* stream);
+
+/* Engine noise -> latent noise (RenderManager._save_frame_data, engine/managers/renderManager.py:926-936):
+ * n = noise*(1-mask) + bg*mask (fp16 product, fp32 sum), 64-pixel row-strip means ("view(-1,8,8,4)"),
+ * then AdaIN against the full-res fp16 noise -> out (1,4,H/8,W/8) fp32.  pooled: (H/8*W/8, 4) fp32. */
+int sr_noise_pool(const void* noise_f16, const void* alpha_f16, const float* bg, float* pooled, float* out,
+                  int32_t H, int32_t W, float* stats, void* stream);
+
+/* CorrespondMap._update (engine/static/corrmap.py:672-736) for ONE frame, deterministic last-writer-wins.
+ * frame (H*W, Cf) fp32 (Cf = 3: alpha 1 appended, corrmap.py:684), ids (H*W,4) int32, mask (H*W) fp32 or NULL
+ * (rows with mask>0 kept), values (k*k, V, 4) fp16, writtens (k*k, V) uint8.  src_index (H*W) int32 or NULL:
+ * colour row used for pixel i (the host reproduces the reference's double-gather quirk by passing it).
+ * winner scratch: k*k*V int32.  mode_first: 1 = skip already-written cells.  Out-of-range (map_index, vid)
+ * -> *err_flag (device int) set to 1 and the row is skipped (the reference raises IndexError). */
+int sr_corrmap_update(const float* frame, int32_t Cf, const int32_t* ids, const float* mask,
+                      const int32_t* src_index, int32_t n_pixels, int32_t sprite, int32_t material,
+                      int32_t check_sprite, int32_t check_material, int32_t mode_first, void* values,
+                      uint8_t* writtens, int32_t kk, int32_t V, int32_t* winner, int32_t* err_flag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Software rasterizer for the G-buffer pass (engine/shaders/default_Gbuffer.{vert,frag}.glsl,
+ * engine/managers/renderManager.py:499-571).  One call = one draw task (mesh x material). */
+typedef struct {
+  const float* pos; const float* normal; const float* uv;   /* per-vertex: [nv,3] [nv,3] [nv,2] fp32 */
+  const float* color;                                       /* [nv,3] or NULL */
+  const int32_t* vertex_id;                                 /* [nv] flat ids (mesh.py:279-281) or NULL */
+  const int32_t* tris;                                      /* [nt,3] */
+  int32_t nv, nt;
+  float MV[16], MV_IT[16], P[16];                           /* column-major as GLM (runtimeManager.py:165-206) */
+  int32_t sprite_id, material_id, corrmap_k, use_texcoord_id, render_mode;  /* 0 normal, 1 baked, 2 baking */
+  int32_t has_vertex_color, depth_test, cull_back;
+  int32_t id_w, id_h;                                       /* texcoord-id grid (diffuse or corr-map size) */
+  const void* noise_tex; int32_t noise_w, noise_h;          /* RGBA16F NEAREST or NULL */
+  const void* diffuse_tex; int32_t diffuse_w, diffuse_h;    /* RGBA32F NEAREST or NULL */
+  const void* corrmap_tex; int32_t corr_w, corr_h;          /* fp16 (k*k, h, w, 4) for render_mode 1 or NULL */
+} sr_draw;
+typedef struct {
+  void* color;      /* [H,W,4] fp16 */
+  int32_t* id;      /* [H,W,4] int32 */
+  float* pos;       /* [H,W,3] fp32 */
+  void* normal_depth; /* [H,W,4] fp16 */
+  void* noise;      /* [H,W,4] fp16 */
+  float* canny;     /* [H,W,3] fp32 */
+  float* zbuf;      /* [H,W] fp32 window-space depth (1.0 = far) */
+  int32_t W, H;
+} sr_gbuffer;
+int sr_gbuffer_clear(const sr_gbuffer* g, void* stream);
+/* scratch: see sr_raster_scratch_bytes(nt, W, H) */
+int sr_raster_draw(const sr_draw* d, const sr_gbuffer* g, void* scratch, int64_t scratch_bytes, void* stream);
+int64_t sr_raster_scratch_bytes(int32_t nt, int32_t W, int32_t H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,140 @@
+"""ctypes binding of libsr_hip.so (C ABI in include/sr_hip.h).  The product path has NO CPU fallback: if
+the shared library is missing or a symbol is absent, import of the compute modules fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsr_hip.so")
+
+SR_F16, SR_F32 = 0, 1
+(OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_TIMESTEP_EMBED, OP_SILU,
+ OP_SOFTMAX_ROWS) = range(1, 10)
+
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+
+
+class IgemmArgs(C.Structure):
+    _fields_ = [("a", vp), ("a2", vp), ("w", vp), ("bias", vp), ("rowvec", vp), ("residual", vp), ("out", vp),
+                ("zero_page", vp), ("B", i32), ("H", i32), ("W", i32), ("C1", i32), ("C2", i32), ("N", i32),
+                ("KH", i32), ("stride", i32), ("upsample", i32), ("act", i32), ("transpose_out", i32), ("ldt", i32),
+                ("out_f32", i32), ("dtype", i32), ("scale", f32)]
+
+
+class GroupNormArgs(C.Structure):
+    _fields_ = [("x", vp), ("x2", vp), ("gamma", vp), ("beta", vp), ("y", vp), ("partials", vp), ("B", i32),
+                ("HW", i32), ("C1", i32), ("C2", i32), ("groups", i32), ("silu", i32), ("dtype", i32), ("eps", f32)]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp), ("B", i32), ("Bk", i32), ("Tq", i32), ("Tk", i32),
+                ("heads", i32), ("d", i32), ("ldt", i32), ("dtype", i32), ("q_stride", i32), ("k_stride", i32),
+                ("scale", f32)]
+
+
+class _Ln(C.Structure):
+    _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("y", vp), ("rows", i32), ("C", i32), ("dtype", i32), ("eps", f32)]
+
+
+class _Cvt(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("per_batch_scale", vp), ("B", i32), ("C", i32), ("HW", i32), ("Cpad", i32),
+                ("dtype", i32), ("ldc", i32), ("scale", f32)]
+
+
+class _Temb(C.Structure):
+    _fields_ = [("t", vp), ("y", vp), ("B", i32), ("dim", i32), ("dtype", i32)]
+
+
+class _Ew(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("n", i64), ("dtype", i32), ("rows", i32), ("cols", i32)]
+
+
+class _OpU(C.Union):
+    _fields_ = [("igemm", IgemmArgs), ("gn", GroupNormArgs), ("attn", AttentionArgs), ("ln", _Ln), ("cvt", _Cvt),
+                ("temb", _Temb), ("ew", _Ew)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("pad_", i32), ("u", _OpU)]
+
+
+class Draw(C.Structure):
+    _fields_ = [("pos", vp), ("normal", vp), ("uv", vp), ("color", vp), ("vertex_id", vp), ("tris", vp), ("nv", i32),
+                ("nt", i32), ("MV", f32 * 16), ("MV_IT", f32 * 16), ("P", f32 * 16), ("sprite_id", i32),
+                ("material_id", i32), ("corrmap_k", i32), ("use_texcoord_id", i32), ("render_mode", i32),
+                ("has_vertex_color", i32), ("depth_test", i32), ("cull_back", i32), ("id_w", i32), ("id_h", i32),
+                ("noise_tex", vp), ("noise_w", i32), ("noise_h", i32), ("diffuse_tex", vp), ("diffuse_w", i32),
+                ("diffuse_h", i32), ("corrmap_tex", vp), ("corr_w", i32), ("corr_h", i32)]
+
+
+class GBuffer(C.Structure):
+    _fields_ = [("color", vp), ("id", vp), ("pos", vp), ("normal_depth", vp), ("noise", vp), ("canny", vp), ("zbuf", vp),
+                ("W", i32), ("H", i32)]
+
+
+# every exported symbol of include/sr_hip.h: name -> (restype, argtypes)
+P = C.POINTER
+SYMBOLS = {
+    "sr_last_error": (C.c_char_p, []),
+    "sr_version": (C.c_int, []),
+    "sr_device_sync": (C.c_int, []),
+    "sr_igemm": (C.c_int, [P(IgemmArgs), vp]),
+    "sr_groupnorm": (C.c_int, [P(GroupNormArgs), vp]),
+    "sr_groupnorm_scratch_floats": (i64, [i32, i32]),
+    "sr_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i32, f32, i32, vp]),
+    "sr_attention": (C.c_int, [P(AttentionArgs), vp]),
+    "sr_nchw_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, vp, i32, vp]),
+    "sr_nhwc_to_nchw": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sr_timestep_embedding": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "sr_silu": (C.c_int, [vp, vp, i64, i32, vp]),
+    "sr_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
+    "sr_softmax_rows": (C.c_int, [vp, i32, i32, i32, vp]),
+    "sr_plan_run": (C.c_int, [P(Op), i32, vp]),
+    "sr_plan_capture": (C.c_int, [P(Op), i32, vp, P(vp)]),
+    "sr_graph_launch": (C.c_int, [vp, vp]),
+    "sr_graph_destroy": (C.c_int, [vp]),
+    "sr_eps_scale_input": (C.c_int, [vp, vp, i64, i32, f32, vp]),
+    "sr_cfg_denoise": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, vp]),
+    "sr_euler_step": (C.c_int, [vp, vp, i64, f32, vp]),
+    "sr_ddpm_step": (C.c_int, [vp, vp, vp, i64, f32, f32, vp]),
+    "sr_lcm_step": (C.c_int, [vp, vp, vp, i64, f32, vp]),
+    "sr_axpby": (C.c_int, [vp, vp, i64, f32, f32, vp]),
+    "sr_idmap_masks": (C.c_int, [vp, vp, i64, vp]),
+    "sr_overlap_build": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "sr_overlap_step": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "sr_adain": (C.c_int, [vp, i64, i64, i64, i32, vp, i32, i64, i64, i64, i32, vp, i32, i32, f32, vp, vp]),
+    "sr_noise_pool": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "sr_corrmap_update": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
+    "sr_gbuffer_clear": (C.c_int, [P(GBuffer), vp]),
+    "sr_raster_draw": (C.c_int, [P(Draw), P(GBuffer), vp, i64, vp]),
+    "sr_raster_scratch_bytes": (i64, [i32, i32, i32]),
+}
+
+_lib = None
+
+
+class SrHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SrHipError("libsr_hip.so not built: run `python stable-renderer_amd/csrc/build.py` "
+                             "(or __graft_entry__.build()); there is no CPU fallback for the product path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SrHipError("libsr_hip: %s (code %d)" % (lib().sr_last_error().decode(errors="replace"), rc))

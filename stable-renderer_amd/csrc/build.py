@@ -1,0 +1,60 @@
+"""Build libsr_hip.so for gfx950 with hipcc (no torch, no cmake): one translation unit per .hip file,
+objects cached under csrc/_obj by source mtime, linked in-tree next to the sources."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "libsr_hip.so")
+SOURCES = ["errors.cpp", "igemm.hip", "norm.hip", "attention.hip", "eltwise.hip", "overlap.hip", "plan.hip", "raster.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+HEADERS = ["sr_common.h", os.path.join("..", "..", "include", "sr_hip.h")]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _needs(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    jobs = []
+    for s in srcs:
+        obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
+        if force or _needs(s, obj):
+            cmd = [cc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(HERE, s), "-o", obj]
+            jobs.append((s, cmd))
+
+    def run(job):
+        s, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr[-4000:]))
+        if verbose:
+            print("compiled", s)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in srcs]
+    if jobs or not os.path.exists(LIB):
+        r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,250 @@
+// Small element-wise kernels: layout/dtype conversion at the UNet/VAE boundary, timestep embedding,
+// row softmax (VAE mid attention) and the sampler arithmetic (EPS scaling, CFG, euler / ddpm / lcm updates).
+// All HBM-bound and tiny next to the MFMA kernels; they exist so the per-step loop never leaves the device.
+#include "sr_common.h"
+
+namespace {
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int HW, int Cpad,
+                                    float scale, const float* __restrict__ pbs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over B*HW*Cpad
+  const int64_t total = (int64_t)B * HW * Cpad;
+  if (i >= total) return;
+  const int c = (int)(i % Cpad);
+  const int64_t bp = i / Cpad;
+  const int p = (int)(bp % HW), b = (int)(bp / HW);
+  float v = 0.f;
+  if (c < C) v = x[((int64_t)b * C + c) * HW + p] * scale * (pbs ? pbs[b] : 1.0f);
+  sr_store_f(y + i, v);
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int HW, int ldc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over B*C*HW (output order)
+  const int64_t total = (int64_t)B * C * HW;
+  if (i >= total) return;
+  const int p = (int)(i % HW);
+  const int64_t bc = i / HW;
+  const int c = (int)(bc % C), b = (int)(bc / C);
+  y[i] = sr_load_f(x + ((int64_t)b * HW + p) * ldc + c);
+}
+
+template <typename T>
+__global__ void temb_kernel(const float* __restrict__ t, T* __restrict__ y, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dim) return;
+  const int b = i / dim, j = i - b * dim, half = dim / 2;
+  const int k = j < half ? j : j - half;
+  // freqs = exp(-ln(10000) * k / half) in fp32, args = t * freqs (util.py:250-256)
+  const float freq = expf(-9.210340371976184f * (float)k / (float)half);
+  const float a = t[b] * freq;
+  sr_store_f(y + i, j < half ? cosf(a) : sinf(a));
+}
+
+template <typename T>
+__global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sr_store_f(y + i, sr_silu_f(sr_load_f(x + i)));
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ x, TD* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sr_store_f(y + i, sr_load_f(x + i));
+}
+
+// in-place row softmax, one block per row (VAE mid-block attention, 4096 keys)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, int cols) {
+  __shared__ float red[4];
+  T* row = x + (int64_t)blockIdx.x * cols;
+  const int tid = threadIdx.x;
+  float mx = -INFINITY;
+  for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, sr_load_f(row + i));
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = tid; i < cols; i += 256) s += __expf(sr_load_f(row + i) - mx);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.0f / s;
+  for (int i = tid; i < cols; i += 256) sr_store_f(row + i, __expf(sr_load_f(row + i) - mx) * inv);
+}
+
+__global__ void eps_scale_kernel(const float* __restrict__ x, float* __restrict__ xin, int64_t n, int copies, float inv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i] * inv;
+  xin[i] = v;
+  if (copies == 2) xin[n + i] = v;
+}
+
+__global__ void cfg_denoise_kernel(const float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ den,
+                                   float* __restrict__ d, int64_t n, int copies, float sigma, float cfg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i];
+  float r;
+  if (copies == 2) {
+    const float u = xv - eps[i] * sigma, c = xv - eps[n + i] * sigma;       // calculate_denoised per chunk
+    r = u + (c - u) * cfg;                                                  // samplers.py:351
+  } else {
+    r = xv - eps[i] * sigma;
+  }
+  den[i] = r;
+  if (d) d[i] = (xv - r) / sigma;                                           // to_d
+}
+
+__global__ void euler_kernel(float* __restrict__ x, const float* __restrict__ d, int64_t n, float dt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = x[i] + d[i] * dt;
+}
+
+// generic_step_sampler + DDPMSampler_step (k_diffusion/sampling.py:749-776), scalars precomputed on the host
+__global__ void ddpm_kernel(float* __restrict__ x, const float* __restrict__ den, const float* __restrict__ noise, int64_t n,
+                            float sigma, float in_scale, float c_mu, float c_eps, float c_noise, float out_scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xv = x[i];
+  const float e = (xv - den[i]) / sigma;
+  float mu = c_mu * (xv * in_scale - c_eps * e);
+  if (noise) mu += c_noise * noise[i];
+  x[i] = mu * out_scale;
+}
+
+__global__ void lcm_kernel(float* __restrict__ x, const float* __restrict__ den, const float* __restrict__ noise, int64_t n, float sn) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = den[i];
+  if (noise) v += sn * noise[i];
+  x[i] = v;
+}
+
+__global__ void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n, float a, float b) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i] + b * y[i];
+}
+
+inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+extern "C" int sr_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t HW, int32_t Cpad, float scale_mul,
+                               const float* pbs, int32_t dtype, void* stream) {
+  if (!x || !y || Cpad < C) SR_FAIL(SR_ERR_INVALID, "sr_nchw_to_nhwc: bad args");
+  const int64_t n = (int64_t)B * HW * Cpad;
+  if (dtype == SR_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<_Float16>, g1(n), dim3(256), 0, sr_stream(stream), x, (_Float16*)y, B, C, HW, Cpad, scale_mul, pbs);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g1(n), dim3(256), 0, sr_stream(stream), x, (float*)y, B, C, HW, Cpad, scale_mul, pbs);
+  SR_CHECK_LAUNCH("sr_nchw_to_nhwc");
+  return SR_OK;
+}
+
+extern "C" int sr_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t HW, int32_t ldc, int32_t dtype, void* stream) {
+  if (!x || !y || ldc < C) SR_FAIL(SR_ERR_INVALID, "sr_nhwc_to_nchw: bad args");
+  const int64_t n = (int64_t)B * HW * C;
+  if (dtype == SR_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, g1(n), dim3(256), 0, sr_stream(stream), (const _Float16*)x, y, B, C, HW, ldc);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, g1(n), dim3(256), 0, sr_stream(stream), (const float*)x, y, B, C, HW, ldc);
+  SR_CHECK_LAUNCH("sr_nhwc_to_nchw");
+  return SR_OK;
+}
+
+extern "C" int sr_timestep_embedding(const float* t, void* y, int32_t B, int32_t dim, int32_t dtype, void* stream) {
+  if (!t || !y || dim % 2) SR_FAIL(SR_ERR_INVALID, "sr_timestep_embedding: bad args");
+  if (dtype == SR_F16) hipLaunchKernelGGL(temb_kernel<_Float16>, g1((int64_t)B * dim), dim3(256), 0, sr_stream(stream), t, (_Float16*)y, B, dim);
+  else hipLaunchKernelGGL(temb_kernel<float>, g1((int64_t)B * dim), dim3(256), 0, sr_stream(stream), t, (float*)y, B, dim);
+  SR_CHECK_LAUNCH("sr_timestep_embedding");
+  return SR_OK;
+}
+
+extern "C" int sr_silu(const void* x, void* y, int64_t n, int32_t dtype, void* stream) {
+  if (!x || !y) SR_FAIL(SR_ERR_INVALID, "sr_silu: null");
+  if (dtype == SR_F16) hipLaunchKernelGGL(silu_kernel<_Float16>, g1(n), dim3(256), 0, sr_stream(stream), (const _Float16*)x, (_Float16*)y, n);
+  else hipLaunchKernelGGL(silu_kernel<float>, g1(n), dim3(256), 0, sr_stream(stream), (const float*)x, (float*)y, n);
+  SR_CHECK_LAUNCH("sr_silu");
+  return SR_OK;
+}
+
+extern "C" int sr_cast(const void* x, int32_t sd, void* y, int32_t dd, int64_t n, void* stream) {
+  if (!x || !y) SR_FAIL(SR_ERR_INVALID, "sr_cast: null");
+  hipStream_t st = sr_stream(stream);
+  if (sd == SR_F32 && dd == SR_F16) hipLaunchKernelGGL((cast_kernel<float, _Float16>), g1(n), dim3(256), 0, st, (const float*)x, (_Float16*)y, n);
+  else if (sd == SR_F16 && dd == SR_F32) hipLaunchKernelGGL((cast_kernel<_Float16, float>), g1(n), dim3(256), 0, st, (const _Float16*)x, (float*)y, n);
+  else if (sd == SR_F32 && dd == SR_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g1(n), dim3(256), 0, st, (const float*)x, (float*)y, n);
+  else hipLaunchKernelGGL((cast_kernel<_Float16, _Float16>), g1(n), dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, n);
+  SR_CHECK_LAUNCH("sr_cast");
+  return SR_OK;
+}
+
+extern "C" int sr_softmax_rows(void* x, int32_t rows, int32_t cols, int32_t dtype, void* stream) {
+  if (!x) SR_FAIL(SR_ERR_INVALID, "sr_softmax_rows: null");
+  if (dtype == SR_F16) hipLaunchKernelGGL(softmax_rows_kernel<_Float16>, dim3(rows), dim3(256), 0, sr_stream(stream), (_Float16*)x, cols);
+  else hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(rows), dim3(256), 0, sr_stream(stream), (float*)x, cols);
+  SR_CHECK_LAUNCH("sr_softmax_rows");
+  return SR_OK;
+}
+
+extern "C" int sr_eps_scale_input(const float* x, float* xin, int64_t n, int32_t copies, float sigma, void* stream) {
+  if (!x || !xin || (copies != 1 && copies != 2)) SR_FAIL(SR_ERR_INVALID, "sr_eps_scale_input: bad args");
+  const float inv = 1.0f / sqrtf(sigma * sigma + 1.0f);     // x / (sigma^2 + 1)^0.5
+  hipLaunchKernelGGL(eps_scale_kernel, g1(n), dim3(256), 0, sr_stream(stream), x, xin, n, copies, inv);
+  SR_CHECK_LAUNCH("sr_eps_scale_input");
+  return SR_OK;
+}
+
+extern "C" int sr_cfg_denoise(const float* x, const float* eps, float* den, float* d, int64_t n, int32_t copies, float sigma,
+                              float cfg, void* stream) {
+  if (!x || !eps || !den || (copies != 1 && copies != 2)) SR_FAIL(SR_ERR_INVALID, "sr_cfg_denoise: bad args");
+  hipLaunchKernelGGL(cfg_denoise_kernel, g1(n), dim3(256), 0, sr_stream(stream), x, eps, den, d, n, copies, sigma, cfg);
+  SR_CHECK_LAUNCH("sr_cfg_denoise");
+  return SR_OK;
+}
+
+extern "C" int sr_euler_step(float* x, const float* d, int64_t n, float dt, void* stream) {
+  if (!x || !d) SR_FAIL(SR_ERR_INVALID, "sr_euler_step: null");
+  hipLaunchKernelGGL(euler_kernel, g1(n), dim3(256), 0, sr_stream(stream), x, d, n, dt);
+  SR_CHECK_LAUNCH("sr_euler_step");
+  return SR_OK;
+}
+
+extern "C" int sr_ddpm_step(float* x, const float* den, const float* noise, int64_t n, float sigma, float sigma_next, void* stream) {
+  if (!x || !den) SR_FAIL(SR_ERR_INVALID, "sr_ddpm_step: null");
+  // scalar algebra of DDPMSampler_step in fp32, as torch does on 0-d fp32 tensors
+  const float in_scale = 1.0f / sqrtf(1.0f + sigma * sigma);
+  const float ac = 1.0f / (sigma * sigma + 1.0f), acp = 1.0f / (sigma_next * sigma_next + 1.0f);
+  const float alpha = ac / acp;
+  const float c_mu = sqrtf(1.0f / alpha);
+  const float c_eps = (1.0f - alpha) / sqrtf(1.0f - ac);
+  float c_noise = 0.f;
+  const float* nz = nullptr;
+  if (sigma_next > 0.f) {
+    if (!noise) SR_FAIL(SR_ERR_INVALID, "sr_ddpm_step: noise required when sigma_next > 0");
+    c_noise = sqrtf((1.0f - alpha) * (1.0f - acp) / (1.0f - ac));
+    nz = noise;
+  }
+  const float out_scale = sigma_next != 0.f ? sqrtf(1.0f + sigma_next * sigma_next) : 1.0f;
+  hipLaunchKernelGGL(ddpm_kernel, g1(n), dim3(256), 0, sr_stream(stream), x, den, nz, n, sigma, in_scale, c_mu, c_eps, c_noise, out_scale);
+  SR_CHECK_LAUNCH("sr_ddpm_step");
+  return SR_OK;
+}
+
+extern "C" int sr_lcm_step(float* x, const float* den, const float* noise, int64_t n, float sigma_next, void* stream) {
+  if (!x || !den) SR_FAIL(SR_ERR_INVALID, "sr_lcm_step: null");
+  const float* nz = sigma_next > 0.f ? noise : nullptr;
+  if (sigma_next > 0.f && !noise) SR_FAIL(SR_ERR_INVALID, "sr_lcm_step: noise required");
+  hipLaunchKernelGGL(lcm_kernel, g1(n), dim3(256), 0, sr_stream(stream), x, den, nz, n, sigma_next);
+  SR_CHECK_LAUNCH("sr_lcm_step");
+  return SR_OK;
+}
+
+extern "C" int sr_axpby(float* y, const float* x, int64_t n, float a, float b, void* stream) {
+  if (!x || !y) SR_FAIL(SR_ERR_INVALID, "sr_axpby: null");
+  hipLaunchKernelGGL(axpby_kernel, g1(n), dim3(256), 0, sr_stream(stream), y, x, n, a, b);
+  SR_CHECK_LAUNCH("sr_axpby");
+  return SR_OK;
+}

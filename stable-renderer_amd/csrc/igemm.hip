@@ -1,0 +1,271 @@
+// Implicit-GEMM convolution / linear layer on gfx950 MFMA (see include/sr_hip.h: sr_igemm).
+//
+// GEMM view:  out[m, n] = sum_k X[m, k] * Wt[n, k],  m = output pixel (b, oy, ox), k = (ky, kx, c).
+// Both operands are K-contiguous, so both LDS tiles are [rows][128 bytes] and are read with the same
+// 16-byte fragment pattern.  Per K-step (128 bytes of K = 64 halfs / 32 floats):
+//   * every wave issues global_load_lds (16 B/lane, async, no VGPR round trip) for its share of the X and W
+//     tiles into the *other* LDS buffer.  The LDS image is lane-linear (8 rows x 8 chunks per wave
+//     instruction), so the XOR swizzle (chunk ^= row&7, conflict-free ds_read_b128) is applied to the SOURCE
+//     address; the im2col gather (tap offsets, zero padding via a zero page, fused nearest-upsample,
+//     stride 2, channel-concat of two sources) is just the per-lane source address.
+//   * each wave multiplies its (BM/WAVES_M) x (BN/WAVES_N) sub-tile with v_mfma_f32_16x16x32_f16 (fp16) or
+//     v_mfma_f32_16x16x4_f32 (exact fp32) out of the current buffer.
+// One barrier per K-step, two LDS buffers.  Weights are the MFMA "A" operand so that every lane ends up
+// holding 4 consecutive output channels of one pixel (8/16-byte stores, vector bias/residual loads); with
+// transpose_out the roles swap and a lane holds 4 consecutive pixels of one channel (V^T for attention).
+#include "sr_common.h"
+
+namespace {
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS>
+__global__ __launch_bounds__(256) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
+                                                    const int NT, const int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KE = 128 / (int)sizeof(T);            // elements of K per step
+  constexpr int NIP = BM / 32, NIQ = BN / 32;          // glds instructions per wave per K-step (X, W tiles)
+  constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = sr_xcd_remap(blockIdx.x, nwg);
+  const int mt = wg / NT, nt = wg - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;                // logical 16-B chunk this lane fetches (source swizzle)
+
+  const int C1 = p.C1, C2 = p.C2, Ctot = C1 + C2;
+  const int K1 = C1 / KE, KPT = Ctot / KE;             // K-steps from source a / per tap
+  const int ntaps = p.KH * p.KH;
+  const int KT = ntaps * KPT;
+  const int H = p.H, W = p.W, pad = p.KH >> 1;
+  const int rpb = Ho * Wo;
+
+  // ---- per-lane row bookkeeping for the X (pixel) tile
+  int pb[NIP], py[NIP], px[NIP];
+#pragma unroll
+  for (int i = 0; i < NIP; ++i) {
+    const int m = m0 + (i * 4 + wv) * 8 + lrow;
+    if (m < M) {
+      const int b = m / rpb, rem = m - b * rpb, oy = rem / Wo;
+      pb[i] = b; py[i] = oy * p.stride - pad; px[i] = (rem - oy * Wo) * p.stride - pad;
+    } else { pb[i] = -1; py[i] = 0; px[i] = 0; }
+  }
+  const char* zp = (const char*)p.zero_page + lchunk * 16;
+  const char* rowA[NIP];
+  const char* rowB[NIP];
+  auto set_tap = [&](int tap) {
+    const int ky = tap / p.KH, kx = tap - ky * p.KH;
+#pragma unroll
+    for (int i = 0; i < NIP; ++i) {
+      int iy = py[i] + ky, ix = px[i] + kx;
+      bool ok = pb[i] >= 0;
+      if (p.upsample) { ok = ok && iy >= 0 && ix >= 0 && iy < 2 * H && ix < 2 * W; iy >>= 1; ix >>= 1; }
+      else            { ok = ok && iy >= 0 && ix >= 0 && iy < H && ix < W; }
+      const int64_t pix = ((int64_t)pb[i] * H + iy) * W + ix;
+      rowA[i] = ok ? (const char*)p.a + (pix * C1) * (int64_t)sizeof(T) + lchunk * 16 : zp;
+      rowB[i] = (ok && C2 > 0) ? (const char*)p.a2 + (pix * C2) * (int64_t)sizeof(T) + lchunk * 16 : zp;
+    }
+  };
+  // ---- W tile rows
+  const char* wrow[NIQ];
+#pragma unroll
+  for (int i = 0; i < NIQ; ++i) {
+    const int n = n0 + (i * 4 + wv) * 8 + lrow;
+    wrow[i] = (const char*)p.w + ((int64_t)n * KT * KE) * (int64_t)sizeof(T) + lchunk * 16;
+  }
+
+  int s_tap = 0, s_kk = 0;
+  set_tap(0);
+  auto stage = [&](int buf) {                            // issue the async loads of the next K-step
+    char* tP = smem + buf * STAGE_BYTES;
+    char* tQ = tP + BM * 128;
+    const bool fromA = s_kk < K1;
+    const int off = (fromA ? s_kk : s_kk - K1) * 128;
+#pragma unroll
+    for (int i = 0; i < NIP; ++i) sr_glds16((fromA ? rowA[i] : rowB[i]) + off, tP + (i * 4 + wv) * 1024);
+#pragma unroll
+    for (int i = 0; i < NIQ; ++i) { sr_glds16(wrow[i], tQ + (i * 4 + wv) * 1024); wrow[i] += 128; }
+    if (++s_kk == KPT) { s_kk = 0; if (++s_tap < ntaps) set_tap(s_tap); }
+  };
+
+  // ---- fragment read offsets
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int wm = wv / WAVES_N, wn = wv - wm * WAVES_N;
+  const int pm0 = wm * (BM / WAVES_M), qn0 = wn * (BN / WAVES_N);
+  int foff[2];
+  foff[0] = c16 * 128 + (((0 + g4) ^ (c16 & 7)) << 4);
+  foff[1] = c16 * 128 + (((4 + g4) ^ (c16 & 7)) << 4);
+
+  constexpr int TA = TRANS ? TM : TN, TB = TRANS ? TN : TM;
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();                                     // (vmcnt(0)+barrier) tile kt landed; buffer kt+1 is free
+    if (kt + 1 < KT) stage((kt + 1) & 1);
+    const char* tP = smem + (kt & 1) * STAGE_BYTES + pm0 * 128;
+    const char* tQ = smem + (kt & 1) * STAGE_BYTES + BM * 128 + qn0 * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint4 xf[TM], wf[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) xf[t] = *(const uint4*)(tP + t * 2048 + foff[j]);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) wf[t] = *(const uint4*)(tQ + t * 2048 + foff[j]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if constexpr (TRANS) sr_mma(acc[tm][tn], xf[tm], wf[tn], T());
+          else                 sr_mma(acc[tn][tm], wf[tn], xf[tm], T());
+        }
+    }
+  }
+
+  // ---- epilogue
+  const float scale = p.scale;
+  const int N = p.N;
+  if constexpr (!TRANS) {
+    const int ldo = (p.act == 2) ? (N >> 1) : N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + pm0 + tm * 16 + c16;
+      if (m >= M) continue;
+      const int b = m / rpb;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + qn0 + tn * 16 + 4 * g4;
+        if (n >= N) continue;
+        float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
+        const int nv = (N - n) < 4 ? (N - n) : 4;
+        if (p.bias) { for (int r = 0; r < nv; ++r) v[r] += p.bias[n + r]; }
+        if (p.rowvec) { for (int r = 0; r < nv; ++r) v[r] += p.rowvec[(int64_t)b * N + n + r]; }
+        if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
+        else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
+        if (p.act == 2) {                                // GEGLU: (value, gate) pairs interleaved along n
+          float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
+          const int64_t oi = (int64_t)m * ldo + (n >> 1);
+          if (p.residual) { o0 += sr_load_f((const T*)p.residual + oi); o1 += sr_load_f((const T*)p.residual + oi + 1); }
+          if (p.out_f32) { float* o = (float*)p.out + oi; o[0] = o0; o[1] = o1; }
+          else { T* o = (T*)p.out + oi; sr_store_f(o, o0); sr_store_f(o + 1, o1); }
+          continue;
+        }
+        const int64_t oi = (int64_t)m * ldo + n;
+        if (nv == 4) {
+          if (p.residual) {
+            if constexpr (sizeof(T) == 2) {
+              const h16x4 rr = *(const h16x4*)((const T*)p.residual + oi);
+              v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
+            } else {
+              const float4 rr = *(const float4*)((const float*)p.residual + oi);
+              v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+          }
+          if (p.out_f32 || sizeof(T) == 4) {
+            *(float4*)((float*)p.out + oi) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *(h16x4*)((_Float16*)p.out + oi) = hv;
+          }
+        } else {
+          for (int r = 0; r < nv; ++r) {
+            float o = v[r];
+            if (p.residual) o += sr_load_f((const T*)p.residual + oi + r);
+            if (p.out_f32) ((float*)p.out)[oi + r] = o; else sr_store_f((T*)p.out + oi + r, o);
+          }
+        }
+      }
+    }
+  } else {
+    const bool vec = (rpb % 4 == 0) && (p.ldt % 4 == 0);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + pm0 + tm * 16 + 4 * g4;
+      if (m >= M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + qn0 + tn * 16 + c16;
+        if (n >= N) continue;
+        const float bz = p.bias ? p.bias[n] : 0.f;
+        float v[4] = {acc[tm][tn][0] * scale + bz, acc[tm][tn][1] * scale + bz, acc[tm][tn][2] * scale + bz,
+                      acc[tm][tn][3] * scale + bz};
+        if (vec) {
+          const int b = m / rpb, t = m - b * rpb;
+          const int64_t oi = ((int64_t)b * N + n) * p.ldt + t;
+          if (p.out_f32 || sizeof(T) == 4) *(float4*)((float*)p.out + oi) = make_float4(v[0], v[1], v[2], v[3]);
+          else { h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; *(h16x4*)((_Float16*)p.out + oi) = hv; }
+        } else {
+          for (int r = 0; r < 4; ++r) {
+            const int mm = m + r;
+            if (mm >= M) break;
+            const int b = mm / rpb, t = mm - b * rpb;
+            const int64_t oi = ((int64_t)b * N + n) * p.ldt + t;
+            if (p.out_f32) ((float*)p.out)[oi] = v[r]; else sr_store_f((T*)p.out + oi, v[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TRANS>
+int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
+  const int Npad = (a.N + 127) / 128 * 128;
+  const int MT = (M + BM - 1) / BM, NT = Npad / BN;
+  // skip all-padding n-tiles
+  const int NTv = (a.N + BN - 1) / BN;
+  const int nwg = MT * NTv;
+  constexpr int lds = 2 * (BM + BN) * 128;
+  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TRANS>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  (void)NT;
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, st, a, M, Ho, Wo, NTv, nwg);
+  SR_CHECK_LAUNCH("sr_igemm");
+  return SR_OK;
+}
+
+template <typename T, bool TRANS>
+int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
+  const int n128 = (a.N + 127) / 128, n64 = (a.N + 63) / 64;
+  const int64_t wg_128x128 = (int64_t)((M + 127) / 128) * n128;
+  const bool waste128 = (n128 * 128 - a.N) * 8 > a.N;          // >12.5% padded columns with BN=128
+  if (!waste128 && wg_128x128 >= 192) return launch<T, 128, 128, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  const int64_t wg_128x64 = (int64_t)((M + 127) / 128) * n64;
+  if (wg_128x64 >= 192) return launch<T, 128, 64, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  return launch<T, 64, 64, 2, 2, TRANS>(a, M, Ho, Wo, st);
+}
+
+}  // namespace
+
+extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
+  if (!a || !a->a || !a->w || !a->out || !a->zero_page) SR_FAIL(SR_ERR_INVALID, "sr_igemm: null pointer");
+  const int ke = a->dtype == SR_F16 ? 64 : 32;
+  if (a->dtype != SR_F16 && a->dtype != SR_F32) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad dtype %d", a->dtype);
+  if (a->C1 <= 0 || a->C1 % ke || a->C2 % ke || a->C2 < 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: C1=%d C2=%d must be multiples of %d", a->C1, a->C2, ke);
+  if (a->C2 > 0 && !a->a2) SR_FAIL(SR_ERR_INVALID, "sr_igemm: C2>0 without a2");
+  if (a->KH != 1 && a->KH != 3) SR_FAIL(SR_ERR_INVALID, "sr_igemm: KH=%d", a->KH);
+  if (a->stride != 1 && a->stride != 2) SR_FAIL(SR_ERR_INVALID, "sr_igemm: stride=%d", a->stride);
+  if (a->upsample && a->stride != 1) SR_FAIL(SR_ERR_INVALID, "sr_igemm: upsample with stride");
+  if (a->N <= 0 || a->B <= 0 || a->H <= 0 || a->W <= 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad sizes");
+  if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
+  int Ho, Wo;
+  if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }
+  else if (a->stride == 2) { Ho = (a->H + 2 * (a->KH / 2) - a->KH) / 2 + 1; Wo = (a->W + 2 * (a->KH / 2) - a->KH) / 2 + 1; }
+  else { Ho = a->H; Wo = a->W; }
+  const int64_t M64 = (int64_t)a->B * Ho * Wo;
+  if (M64 > 0x7fffffffLL / 2) SR_FAIL(SR_ERR_INVALID, "sr_igemm: M too large");
+  const int M = (int)M64;
+  if (a->transpose_out && a->ldt < Ho * Wo) SR_FAIL(SR_ERR_INVALID, "sr_igemm: ldt < pixels per batch");
+  hipStream_t st = sr_stream(stream);
+  if (a->dtype == SR_F16) {
+    return a->transpose_out ? dispatch<_Float16, true>(*a, M, Ho, Wo, st) : dispatch<_Float16, false>(*a, M, Ho, Wo, st);
+  }
+  return a->transpose_out ? dispatch<float, true>(*a, M, Ho, Wo, st) : dispatch<float, false>(*a, M, Ho, Wo, st);
+}

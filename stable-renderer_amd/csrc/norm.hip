@@ -1,0 +1,239 @@
+// GroupNorm(+SiLU) and LayerNorm over NHWC activations — HBM-bound streaming kernels (16 B/lane accesses).
+//
+// GroupNorm: pass 1 accumulates per-channel sum / sum-of-squares in registers (every thread owns a fixed
+// 16-byte channel chunk and walks pixels, so loads are fully coalesced along C), folds them to the 32 groups
+// in LDS and writes one fp32 partial per (batch, pixel-chunk, group) — no float atomics, so results are
+// bit-reproducible.  Pass 2 reduces the partials of its batch entry in a fixed order, builds per-channel
+// scale/shift in LDS and applies y = x*sc + sh (+SiLU).  Both passes can read the channel concat of two
+// sources, which is how the decoder's th.cat([h, skip]) is consumed without materialising it.
+#include "sr_common.h"
+
+namespace {
+
+constexpr int GN_PIX_PER_CHUNK = 64;
+
+template <typename T>
+__device__ __forceinline__ void load_chunk(const T* p, float (&v)[sr_traits<T>::EPC]) {
+  if constexpr (sizeof(T) == 2) {
+    const h16x8 h = *(const h16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+  } else {
+    const float4 f = *(const float4*)p;
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_chunk(T* p, const float (&v)[sr_traits<T>::EPC]) {
+  if constexpr (sizeof(T) == 2) {
+    h16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+    *(h16x8*)p = h;
+  } else {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// grid (nchunk, B), block 256.  partials[b][chunk][group][2]
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x1, const T* __restrict__ x2, float* __restrict__ partials,
+                                                       int HW, int C1, int C2, int groups, int nchunk) {
+  constexpr int EPC = sr_traits<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int C = C1 + C2, cpt = C / EPC, cpg = C / groups;
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int pp_ = 256 / cpt;
+  const int nps = pp_ >= 1 ? pp_ : 1;               // pixel slices held in LDS
+  float* chs = (float*)smem_raw;                    // [nps][C] per-channel sums
+  float* chq = chs + nps * C;                       // [nps][C] per-channel sums of squares
+  const int p0 = chunk * GN_PIX_PER_CHUNK;
+  const int p1 = min(HW, p0 + GN_PIX_PER_CHUNK);
+  const int pp = 256 / cpt;                        // pixels processed in parallel when cpt <= 256
+  if (pp >= 1) {
+    const int cc = tid % cpt, ps = tid / cpt;
+    if (ps < pp) {
+      float s[EPC], q[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      const int c0 = cc * EPC;
+      const T* src = c0 < C1 ? x1 + (int64_t)b * HW * C1 + c0 : x2 + (int64_t)b * HW * C2 + (c0 - C1);
+      const int cs = c0 < C1 ? C1 : C2;
+      for (int p = p0 + ps; p < p1; p += pp) {
+        float v[EPC];
+        load_chunk<T>(src + (int64_t)p * cs, v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { chs[ps * C + c0 + e] = s[e]; chq[ps * C + c0 + e] = q[e]; }
+    }
+  } else {
+    for (int cc = tid; cc < cpt; cc += 256) {
+      float s[EPC], q[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      const int c0 = cc * EPC;
+      const T* src = c0 < C1 ? x1 + (int64_t)b * HW * C1 + c0 : x2 + (int64_t)b * HW * C2 + (c0 - C1);
+      const int cs = c0 < C1 ? C1 : C2;
+      for (int p = p0; p < p1; ++p) {
+        float v[EPC];
+        load_chunk<T>(src + (int64_t)p * cs, v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { chs[c0 + e] = s[e]; chq[c0 + e] = q[e]; }
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {                               // fixed summation order -> bit-reproducible
+    float gs = 0.f, gq = 0.f;
+    for (int ps = 0; ps < nps; ++ps)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { gs += chs[ps * C + c]; gq += chq[ps * C + c]; }
+    float* o = partials + (((int64_t)b * nchunk + chunk) * groups + tid) * 2;
+    o[0] = gs; o[1] = gq;
+  }
+}
+
+// grid (nchunk, B), block 256; dynamic LDS: 2*C floats (scale/shift per channel)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const float* __restrict__ partials,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                                       int HW, int C1, int C2, int groups, int nchunk, float eps, int silu) {
+  constexpr int EPC = sr_traits<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sc = (float*)smem_raw;
+  const int C = C1 + C2, cpt = C / EPC, cpg = C / groups;
+  float* sh = sc + C;
+  float* gm = sh + C;      // [groups] mean, [groups] rstd
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  if (tid < groups) {
+    double s = 0.0, q = 0.0;                       // fixed-order reduction of the partials
+    const float* pp = partials + ((int64_t)b * nchunk * groups + tid) * 2;
+    for (int i = 0; i < nchunk; ++i) { s += pp[(int64_t)i * groups * 2]; q += pp[(int64_t)i * groups * 2 + 1]; }
+    const double cnt = (double)HW * cpg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gm[tid] = (float)mean;
+    gm[groups + tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float a = gm[groups + g] * gamma[c];
+    sc[c] = a; sh[c] = beta[c] - gm[g] * a;
+  }
+  __syncthreads();
+  const int p0 = chunk * GN_PIX_PER_CHUNK;
+  const int p1 = min(HW, p0 + GN_PIX_PER_CHUNK);
+  const int total = (p1 - p0) * cpt;
+  for (int idx = tid; idx < total; idx += 256) {
+    const int p = p0 + idx / cpt, cc = idx - (idx / cpt) * cpt;
+    const int c0 = cc * EPC;
+    const T* src = c0 < C1 ? x1 + ((int64_t)b * HW + p) * C1 + c0 : x2 + ((int64_t)b * HW + p) * C2 + (c0 - C1);
+    float v[EPC];
+    load_chunk<T>(src, v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float t = v[e] * sc[c0 + e] + sh[c0 + e];
+      v[e] = silu ? sr_silu_f(t) : t;
+    }
+    store_chunk<T>(y + ((int64_t)b * HW + p) * C + c0, v);
+  }
+}
+
+// one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        T* __restrict__ y, int rows, int C, float eps) {
+  constexpr int EPC = sr_traits<T>::EPC;
+  constexpr int MAXC = 5;                           // chunks per lane: C <= 64*5*EPC (2560 fp16 / 1280 fp32)
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int cpt = C / EPC;
+  float v[MAXC][EPC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cc = lane + i * 64;
+    if (cc < cpt) {
+      load_chunk<T>(x + (int64_t)row * C + cc * EPC, v[i]);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s += v[i][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cc = lane + i * 64;
+    if (cc < cpt) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cc = lane + i * 64;
+    if (cc < cpt) {
+      float o[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[cc * EPC + e] + beta[cc * EPC + e];
+      store_chunk<T>(y + (int64_t)row * C + cc * EPC, o);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t sr_groupnorm_scratch_floats(int32_t B, int32_t HW) {
+  return (int64_t)B * sr_cdiv(HW, GN_PIX_PER_CHUNK) * 64 * 2;
+}
+
+extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
+  if (!a || !a->x || !a->y || !a->gamma || !a->beta || !a->partials) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: null pointer");
+  const int epc = a->dtype == SR_F16 ? 8 : 4;
+  const int C = a->C1 + a->C2;
+  if (a->groups <= 0 || a->groups > 64 || C % a->groups) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C=%d groups=%d", C, a->groups);
+  if (a->C1 % epc || a->C2 % epc) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: channels must be multiples of %d", epc);
+  if (a->C2 > 0 && !a->x2) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C2>0 without x2");
+  const int nchunk = sr_cdiv(a->HW, GN_PIX_PER_CHUNK);
+  const size_t lds = (size_t)(2 * C + 2 * a->groups) * sizeof(float);
+  if (lds > 64 * 1024) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C too large");
+  hipStream_t st = sr_stream(stream);
+  dim3 grid(nchunk, a->B);
+  const int cpt = C / epc, nps = 256 / cpt >= 1 ? 256 / cpt : 1;
+  const size_t lds_stats = (size_t)2 * nps * C * sizeof(float);
+  if (a->dtype == SR_F16) {
+    hipLaunchKernelGGL(gn_stats_kernel<_Float16>, grid, dim3(256), lds_stats, st, (const _Float16*)a->x, (const _Float16*)a->x2, a->partials, a->HW, a->C1, a->C2, a->groups, nchunk);
+    hipLaunchKernelGGL(gn_apply_kernel<_Float16>, grid, dim3(256), lds, st, (const _Float16*)a->x, (const _Float16*)a->x2, a->partials, a->gamma, a->beta,
+                       (_Float16*)a->y, a->HW, a->C1, a->C2, a->groups, nchunk, a->eps, a->silu);
+  } else if (a->dtype == SR_F32) {
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), lds_stats, st, (const float*)a->x, (const float*)a->x2, a->partials, a->HW, a->C1, a->C2, a->groups, nchunk);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), lds, st, (const float*)a->x, (const float*)a->x2, a->partials, a->gamma, a->beta,
+                       (float*)a->y, a->HW, a->C1, a->C2, a->groups, nchunk, a->eps, a->silu);
+  } else SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: dtype");
+  SR_CHECK_LAUNCH("sr_groupnorm");
+  return SR_OK;
+}
+
+extern "C" int sr_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t rows, int32_t C,
+                            float eps, int32_t dtype, void* stream) {
+  if (!x || !y || !gamma || !beta) SR_FAIL(SR_ERR_INVALID, "sr_layernorm: null pointer");
+  const int epc = dtype == SR_F16 ? 8 : 4;
+  if (C % epc || C / epc > 64 * 5) SR_FAIL(SR_ERR_INVALID, "sr_layernorm: C=%d unsupported", C);
+  hipStream_t st = sr_stream(stream);
+  dim3 grid(sr_cdiv(rows, 4));
+  if (dtype == SR_F16) hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)x, gamma, beta, (_Float16*)y, rows, C, eps);
+  else if (dtype == SR_F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, rows, C, eps);
+  else SR_FAIL(SR_ERR_INVALID, "sr_layernorm: dtype");
+  SR_CHECK_LAUNCH("sr_layernorm");
+  return SR_OK;
+}

@@ -1,0 +1,282 @@
+// Stable-rendering kernels: id-map masks, latent-overlap (OverlapCorresponder.step_finished), AdaIN, engine-noise
+// pooling and CorrespondMap update.  All are HBM/L2-bound gather/scatter work on int32 id maps and small fp32
+// latents; duplicate scatter targets are resolved deterministically as "last row wins" (= the reference's
+// sequential CPU index_put_) with an integer atomicMax on the row index instead of racing stores.
+#include "sr_common.h"
+
+namespace {
+
+constexpr int NON_AI = 2048;
+
+__device__ __forceinline__ bool id_valid(const int4 v) {
+  return v.z != NON_AI && (v.x != 0 || v.y != 0 || v.z != 0 || v.w != 0);
+}
+
+__global__ void idmap_masks_kernel(const int4* __restrict__ ids, float* __restrict__ masks, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 v = ids[i];
+  masks[i] = (v.z == NON_AI || (v.x == 0 && v.y == 0 && v.z == 0 && v.w == 0)) ? 1.0f : 0.0f;
+}
+
+// pixel -> latent cell with the reference's fp32 arithmetic: x_ratio = x / H, y_ratio = y / W (sic,
+// corrmap.py:243,252), cell = int(ratio * latent_size) (corresponder.py:312-313)
+__device__ __forceinline__ int cell_of(int f, int y, int x, int H, int W, int lh, int lw, bool* ok) {
+  const float xr = (float)x / (float)H, yr = (float)y / (float)W;
+  const int sx = (int)(xr * (float)lw), sy = (int)(yr * (float)lh);
+  *ok = sx < lw && sy < lh;
+  return (f * lh + sy) * lw + sx;
+}
+
+// info[0] = max vid, info[1] = out-of-range flag, info[2] = #valid pixels
+__global__ void overlap_build1(const int4* __restrict__ ids, int N, int H, int W, int lh, int lw, int* __restrict__ pix_cell,
+                               int* __restrict__ cell_win, int* __restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)N * H * W;
+  if (i >= total) return;
+  const int4 v = ids[i];
+  int cell = -1;
+  if (id_valid(v)) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), f = (int)(i / ((int64_t)W * H));
+    bool ok;
+    cell = cell_of(f, y, x, H, W, lh, lw, &ok);
+    if (!ok || v.w < 0) { atomicOr(&info[1], 1); cell = -1; }
+    else {
+      atomicMax(&cell_win[cell], (int)i);                  // last (f,y,x) pixel of the cell wins the scatter
+      atomicMax(&info[0], v.w);
+      atomicAdd(&info[2], 1);
+    }
+  }
+  pix_cell[i] = cell;
+}
+__global__ void overlap_build2(const int4* __restrict__ ids, int ncell, const int* __restrict__ cell_win, int* __restrict__ cell_vid) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int w = cell_win[c];
+  cell_vid[c] = w >= 0 ? ids[w].w : -1;
+}
+
+__global__ void overlap_accum(const float* __restrict__ x, const int4* __restrict__ ids, const int* __restrict__ pix_cell, int64_t npix,
+                              int C, int lhw, int cap, float* __restrict__ vsum) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const int cell = pix_cell[i];
+  if (cell < 0) return;
+  const int vid = ids[i].w;
+  if (vid >= cap) return;
+  const int f = cell / lhw, p = cell - f * lhw;
+  float* dst = vsum + (int64_t)vid * (C + 1);
+  for (int c = 0; c < C; ++c) atomicAdd(dst + c, x[((int64_t)f * C + c) * lhw + p]);
+  atomicAdd(dst + C, 1.0f);
+}
+
+// block reduction helpers (fixed order -> reproducible)
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
+}
+
+// one block per (n, c) plane: blended plane -> stats -> AdaIN -> x (in place)
+__global__ __launch_bounds__(256) void overlap_apply(float* __restrict__ x, const int* __restrict__ cell_vid, const float* __restrict__ vsum,
+                                                     int C, int lhw, int cap, float ratio, float eps, float* __restrict__ blended_out) {
+  __shared__ float red[4];
+  const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+  float* xp = x + (int64_t)blockIdx.x * lhw;
+  const int* cv = cell_vid + (int64_t)n * lhw;
+  auto blend = [&](int p) -> float {
+    const float xv = xp[p];
+    const int vid = cv[p];
+    if (vid < 0 || vid >= cap) return xv;
+    const float* s = vsum + (int64_t)vid * (C + 1);
+    const float mean = s[c] / s[C];
+    return (1.0f - ratio) * xv + ratio * mean;
+  };
+  float sc = 0.f, ss = 0.f;
+  for (int p = threadIdx.x; p < lhw; p += 256) { sc += xp[p]; ss += blend(p); }
+  const float mc = block_sum(sc, red) / (float)lhw;
+  const float ms = block_sum(ss, red) / (float)lhw;
+  float qc = 0.f, qs = 0.f;
+  for (int p = threadIdx.x; p < lhw; p += 256) {
+    const float a = xp[p] - mc, b = blend(p) - ms;
+    qc += a * a; qs += b * b;
+  }
+  const float stdc = sqrtf(block_sum(qc, red) / (float)(lhw - 1) + eps);
+  const float stds = sqrtf(block_sum(qs, red) / (float)(lhw - 1) + eps);
+  __syncthreads();
+  for (int p = threadIdx.x; p < lhw; p += 256) {
+    const float bv = blend(p);
+    if (blended_out) blended_out[(int64_t)blockIdx.x * lhw + p] = bv;
+    xp[p] = (xp[p] - mc) / stdc * stds + ms;
+  }
+}
+
+// generic AdaIN: one block per (n,c)
+template <typename TS>
+__global__ __launch_bounds__(256) void adain_kernel(const float* __restrict__ content, int64_t c_ps, int64_t c_cs, int64_t c_ns, int HWc,
+                                                    const TS* __restrict__ style, int64_t s_ps, int64_t s_cs, int64_t s_ns, int HWs,
+                                                    float* __restrict__ out, int C, float eps, int half_stats) {
+  __shared__ float red[4];
+  const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+  const float* cp = content + n * c_ns + c * c_cs;
+  const TS* sp = style + n * s_ns + c * s_cs;
+  float a = 0.f, b = 0.f;
+  for (int p = threadIdx.x; p < HWc; p += 256) a += cp[p * c_ps];
+  for (int p = threadIdx.x; p < HWs; p += 256) b += sr_load_f(sp + p * s_ps);
+  const float mc = block_sum(a, red) / (float)HWc;
+  float ms = block_sum(b, red) / (float)HWs;
+  a = 0.f; b = 0.f;
+  for (int p = threadIdx.x; p < HWc; p += 256) { const float t = cp[p * c_ps] - mc; a += t * t; }
+  for (int p = threadIdx.x; p < HWs; p += 256) { const float t = sr_load_f(sp + p * s_ps) - ms; b += t * t; }
+  const float varc = block_sum(a, red) / (float)(HWc - 1) + eps;
+  float vars = block_sum(b, red) / (float)(HWs - 1);
+  float stds;
+  if (half_stats) {
+    // style is an fp16 tensor in the reference: var / +eps / mean are rounded to fp16, sqrt in fp32, std -> fp16
+    const _Float16 v16 = (_Float16)((float)(_Float16)vars + (float)(_Float16)eps);
+    stds = (float)(_Float16)sqrtf((float)v16);
+    ms = (float)(_Float16)ms;
+  } else {
+    stds = sqrtf(vars + eps);
+  }
+  const float stdc = sqrtf(varc);
+  float* op = out + (int64_t)blockIdx.x * HWc;
+  for (int p = threadIdx.x; p < HWc; p += 256) op[p] = (cp[p * c_ps] - mc) / stdc * stds + ms;
+}
+
+// 64-pixel strip means of noise*(1-mask) + bg*mask (renderManager.py:929-932)
+__global__ void noise_pool_kernel(const _Float16* __restrict__ noise, const _Float16* __restrict__ alpha, const float* __restrict__ bg,
+                                  float* __restrict__ pooled, int ngroups) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // over ngroups*4
+  if (i >= ngroups * 4) return;
+  const int g = i >> 2, c = i & 3;
+  float s = 0.f;
+  for (int k = 0; k < 64; ++k) {
+    const int64_t px = (int64_t)g * 64 + k;
+    const _Float16 m = (_Float16)(1.0f - (float)alpha[px]);            // mask = 1 - alpha (fp16)
+    const _Float16 om = (_Float16)(1.0f - (float)m);
+    const _Float16 a = (_Float16)((float)noise[px * 4 + c] * (float)om); // fp16 product
+    s += (float)a + bg[px * 4 + c] * (float)m;
+  }
+  pooled[i] = s * (1.0f / 64.0f);
+}
+
+__global__ void corrmap_pass1(const int4* __restrict__ ids, const float* __restrict__ mask, int n, int sprite, int material, int chk_s,
+                              int chk_m, int mode_first, const uint8_t* __restrict__ writtens, int kk, int V, int* __restrict__ winner,
+                              int* __restrict__ err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mask && !(mask[i] > 0.f)) return;
+  const int4 v = ids[i];
+  if (chk_s && v.x != sprite) return;
+  if (chk_m && v.y != material) return;
+  if (v.z < 0 || v.z >= kk || v.w < 0 || v.w >= V) { atomicOr(err, 1); return; }
+  const int cell = v.z * V + v.w;
+  if (mode_first && writtens[cell]) return;
+  atomicMax(&winner[cell], i);
+}
+__global__ void corrmap_pass2(const float* __restrict__ frame, int Cf, const int4* __restrict__ ids, const int* __restrict__ src_index, int n,
+                              int V, const int* __restrict__ winner, _Float16* __restrict__ values, uint8_t* __restrict__ writtens) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 v = ids[i];
+  if (v.z < 0 || v.w < 0 || v.w >= V) return;
+  const int cell = v.z * V + v.w;
+  if (winner[cell] != i) return;                           // (cells of filtered rows keep winner == -1 / other)
+  const int64_t src = src_index ? src_index[i] : i;
+  const float* cp = frame + src * Cf;
+  _Float16* o = values + (int64_t)cell * 4;
+  o[0] = (_Float16)cp[0]; o[1] = (_Float16)cp[1]; o[2] = (_Float16)cp[2];
+  o[3] = Cf >= 4 ? (_Float16)cp[3] : (_Float16)1.0f;
+  writtens[cell] = 1;
+}
+
+inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+extern "C" int sr_idmap_masks(const int32_t* ids, float* masks, int64_t n, void* stream) {
+  if (!ids || !masks) SR_FAIL(SR_ERR_INVALID, "sr_idmap_masks: null");
+  hipLaunchKernelGGL(idmap_masks_kernel, g1(n), dim3(256), 0, sr_stream(stream), (const int4*)ids, masks, n);
+  SR_CHECK_LAUNCH("sr_idmap_masks");
+  return SR_OK;
+}
+
+extern "C" int sr_overlap_build(const int32_t* ids, int32_t N, int32_t H, int32_t W, int32_t lh, int32_t lw, int32_t* pix_cell,
+                                int32_t* cell_vid, int32_t* info, void* stream) {
+  if (!ids || !pix_cell || !cell_vid || !info) SR_FAIL(SR_ERR_INVALID, "sr_overlap_build: null");
+  hipStream_t st = sr_stream(stream);
+  const int ncell = N * lh * lw;
+  // cell_vid doubles as the winner table during pass 1
+  if (hipMemsetAsync(cell_vid, 0xFF, (size_t)ncell * 4, st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "memset");
+  if (hipMemsetAsync(info, 0, 16, st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "memset");
+  const int64_t npix = (int64_t)N * H * W;
+  hipLaunchKernelGGL(overlap_build1, g1(npix), dim3(256), 0, st, (const int4*)ids, N, H, W, lh, lw, pix_cell, cell_vid, info);
+  hipLaunchKernelGGL(overlap_build2, g1(ncell), dim3(256), 0, st, (const int4*)ids, ncell, cell_vid, cell_vid);
+  SR_CHECK_LAUNCH("sr_overlap_build");
+  return SR_OK;
+}
+
+extern "C" int sr_overlap_step(float* x, const int32_t* ids, const int32_t* pix_cell, const int32_t* cell_vid, int32_t N, int32_t C,
+                               int32_t H, int32_t W, int32_t lh, int32_t lw, int32_t cap, float ratio, float* vsum, float* blended,
+                               float* stats, void* stream) {
+  (void)stats;
+  if (!x || !ids || !pix_cell || !cell_vid || !vsum) SR_FAIL(SR_ERR_INVALID, "sr_overlap_step: null");
+  if (lh * lw < 2) SR_FAIL(SR_ERR_INVALID, "sr_overlap_step: latent too small");
+  hipStream_t st = sr_stream(stream);
+  if (hipMemsetAsync(vsum, 0, (size_t)cap * (C + 1) * sizeof(float), st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "memset");
+  const int64_t npix = (int64_t)N * H * W;
+  hipLaunchKernelGGL(overlap_accum, g1(npix), dim3(256), 0, st, x, (const int4*)ids, pix_cell, npix, C, lh * lw, cap, vsum);
+  hipLaunchKernelGGL(overlap_apply, dim3(N * C), dim3(256), 0, st, x, cell_vid, vsum, C, lh * lw, cap, ratio, 1e-5f, blended);
+  SR_CHECK_LAUNCH("sr_overlap_step");
+  return SR_OK;
+}
+
+extern "C" int sr_adain(const float* content, int64_t c_ps, int64_t c_cs, int64_t c_ns, int32_t HWc, const void* style,
+                        int32_t style_dtype, int64_t s_ps, int64_t s_cs, int64_t s_ns, int32_t HWs, float* out, int32_t N, int32_t C,
+                        float eps, float* stats, void* stream) {
+  (void)stats;
+  if (!content || !style || !out || HWc < 2 || HWs < 2) SR_FAIL(SR_ERR_INVALID, "sr_adain: bad args");
+  hipStream_t st = sr_stream(stream);
+  if (style_dtype == SR_F16)
+    hipLaunchKernelGGL(adain_kernel<_Float16>, dim3(N * C), dim3(256), 0, st, content, c_ps, c_cs, c_ns, HWc, (const _Float16*)style, s_ps,
+                       s_cs, s_ns, HWs, out, C, eps, 1);
+  else
+    hipLaunchKernelGGL(adain_kernel<float>, dim3(N * C), dim3(256), 0, st, content, c_ps, c_cs, c_ns, HWc, (const float*)style, s_ps, s_cs,
+                       s_ns, HWs, out, C, eps, 0);
+  SR_CHECK_LAUNCH("sr_adain");
+  return SR_OK;
+}
+
+extern "C" int sr_noise_pool(const void* noise_f16, const void* alpha_f16, const float* bg, float* pooled, float* out, int32_t H,
+                             int32_t W, float* stats, void* stream) {
+  (void)stats;
+  if (!noise_f16 || !alpha_f16 || !bg || !pooled || !out) SR_FAIL(SR_ERR_INVALID, "sr_noise_pool: null");
+  if (H % 8 || W % 8 || (H * W) % 64) SR_FAIL(SR_ERR_INVALID, "sr_noise_pool: H,W must be multiples of 8");
+  hipStream_t st = sr_stream(stream);
+  const int ng = H * W / 64;
+  hipLaunchKernelGGL(noise_pool_kernel, g1((int64_t)ng * 4), dim3(256), 0, st, (const _Float16*)noise_f16, (const _Float16*)alpha_f16, bg, pooled, ng);
+  // AdaIN(content = pooled NHWC (1,h,w,4), style = full-res fp16 noise NHWC) -> (1,4,h,w)
+  hipLaunchKernelGGL(adain_kernel<_Float16>, dim3(4), dim3(256), 0, st, pooled, (int64_t)4, (int64_t)1, (int64_t)0, ng, (const _Float16*)noise_f16,
+                     (int64_t)4, (int64_t)1, (int64_t)0, H * W, out, 4, 1e-5f, 1);
+  SR_CHECK_LAUNCH("sr_noise_pool");
+  return SR_OK;
+}
+
+extern "C" int sr_corrmap_update(const float* frame, int32_t Cf, const int32_t* ids, const float* mask, const int32_t* src_index,
+                                 int32_t n, int32_t sprite, int32_t material, int32_t chk_s, int32_t chk_m, int32_t mode_first,
+                                 void* values, uint8_t* writtens, int32_t kk, int32_t V, int32_t* winner, int32_t* err, void* stream) {
+  if (!frame || !ids || !values || !writtens || !winner || !err) SR_FAIL(SR_ERR_INVALID, "sr_corrmap_update: null");
+  if (Cf != 3 && Cf != 4) SR_FAIL(SR_ERR_INVALID, "sr_corrmap_update: Cf must be 3 or 4");
+  hipStream_t st = sr_stream(stream);
+  if (hipMemsetAsync(winner, 0xFF, (size_t)kk * V * 4, st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "memset");
+  hipLaunchKernelGGL(corrmap_pass1, g1(n), dim3(256), 0, st, (const int4*)ids, mask, n, sprite, material, chk_s, chk_m, mode_first, writtens, kk, V,
+                     winner, err);
+  hipLaunchKernelGGL(corrmap_pass2, g1(n), dim3(256), 0, st, frame, Cf, (const int4*)ids, src_index, n, V, winner, (_Float16*)values, writtens);
+  SR_CHECK_LAUNCH("sr_corrmap_update");
+  return SR_OK;
+}

@@ -1,0 +1,72 @@
+// Launch-plan executor: the Python host lowers a model (UNet / VAE decoder / ControlNet encoder) to a flat
+// array of sr_op once per (weights, batch, resolution); every denoise step then replays it from native code —
+// either eagerly (sr_plan_run) or as a captured hipGraph (sr_plan_capture / sr_graph_launch), so the per-step
+// hot loop has no Python, no allocation and no host synchronisation in it.
+#include "sr_common.h"
+
+static int run_op(const sr_op& op, void* stream) {
+  switch (op.kind) {
+    case SR_OP_IGEMM: return sr_igemm(&op.u.igemm, stream);
+    case SR_OP_GROUPNORM: return sr_groupnorm(&op.u.gn, stream);
+    case SR_OP_ATTENTION: return sr_attention(&op.u.attn, stream);
+    case SR_OP_LAYERNORM:
+      return sr_layernorm(op.u.ln.x, op.u.ln.gamma, op.u.ln.beta, op.u.ln.y, op.u.ln.rows, op.u.ln.C, op.u.ln.eps, op.u.ln.dtype, stream);
+    case SR_OP_NCHW_TO_NHWC:
+      return sr_nchw_to_nhwc((const float*)op.u.cvt.x, op.u.cvt.y, op.u.cvt.B, op.u.cvt.C, op.u.cvt.HW, op.u.cvt.Cpad, op.u.cvt.scale,
+                             op.u.cvt.per_batch_scale, op.u.cvt.dtype, stream);
+    case SR_OP_NHWC_TO_NCHW:
+      return sr_nhwc_to_nchw(op.u.cvt.x, (float*)op.u.cvt.y, op.u.cvt.B, op.u.cvt.C, op.u.cvt.HW, op.u.cvt.ldc, op.u.cvt.dtype, stream);
+    case SR_OP_TIMESTEP_EMBED:
+      return sr_timestep_embedding(op.u.temb.t, op.u.temb.y, op.u.temb.B, op.u.temb.dim, op.u.temb.dtype, stream);
+    case SR_OP_SILU: return sr_silu(op.u.ew.x, op.u.ew.y, op.u.ew.n, op.u.ew.dtype, stream);
+    case SR_OP_SOFTMAX_ROWS: return sr_softmax_rows(op.u.ew.y, op.u.ew.rows, op.u.ew.cols, op.u.ew.dtype, stream);
+    default: sr_set_error("sr_plan_run: unknown op kind %d", op.kind); return SR_ERR_INVALID;
+  }
+}
+
+extern "C" int sr_plan_run(const sr_op* ops, int32_t n, void* stream) {
+  if (!ops || n < 0) SR_FAIL(SR_ERR_INVALID, "sr_plan_run: bad args");
+  for (int i = 0; i < n; ++i) {
+    const int rc = run_op(ops[i], stream);
+    if (rc != SR_OK) {
+      char buf[400];
+      snprintf(buf, sizeof(buf), "%s", sr_last_error());
+      sr_set_error("plan op %d (kind %d): %s", i, ops[i].kind, buf);
+      return rc;
+    }
+  }
+  return SR_OK;
+}
+
+extern "C" int sr_plan_capture(const sr_op* ops, int32_t n, void* stream, void** graph_exec) {
+  if (!ops || !graph_exec || !stream) SR_FAIL(SR_ERR_INVALID, "sr_plan_capture: needs a non-default stream");
+  hipStream_t st = sr_stream(stream);
+  // warm every kernel once outside the capture (function attributes are set lazily on first launch)
+  int rc = sr_plan_run(ops, n, stream);
+  if (rc != SR_OK) return rc;
+  if (hipStreamSynchronize(st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "sr_plan_capture: warm-up failed: %s", hipGetErrorString(hipGetLastError()));
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "sr_plan_capture: begin capture failed");
+  rc = sr_plan_run(ops, n, stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != SR_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess || !graph) SR_FAIL(SR_ERR_LAUNCH, "sr_plan_capture: end capture: %s", hipGetErrorString(e));
+  hipGraphExec_t ex = nullptr;
+  const hipError_t e2 = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e2 != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "sr_plan_capture: instantiate: %s", hipGetErrorString(e2));
+  *graph_exec = (void*)ex;
+  return SR_OK;
+}
+
+extern "C" int sr_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) SR_FAIL(SR_ERR_INVALID, "sr_graph_launch: null");
+  const hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, sr_stream(stream));
+  if (e != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "sr_graph_launch: %s", hipGetErrorString(e));
+  return SR_OK;
+}
+
+extern "C" int sr_graph_destroy(void* graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return SR_OK;
+}

@@ -1,0 +1,60 @@
+// Shared device/host helpers for libsr_hip (gfx950 only: wave64, MFMA 16x16x32 f16 / 16x16x4 f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/sr_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+void sr_set_error(const char* fmt, ...);
+#define SR_FAIL(code, ...) do { sr_set_error(__VA_ARGS__); return (code); } while (0)
+#define SR_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    sr_set_error("%s: %s", name, hipGetErrorString(e_)); return SR_ERR_LAUNCH; } } while (0)
+
+template <typename T> struct sr_traits;
+template <> struct sr_traits<_Float16> { static constexpr int EPC = 8;  /* elements per 16-byte chunk */ };
+template <> struct sr_traits<float>    { static constexpr int EPC = 4; };
+
+// One "macro step" of the 16x16 MFMA family on a pair of 16-byte operand chunks (lane (g = lane>>4,
+// c = lane&15) holds row/col c, k-slots [g*EPC, g*EPC+EPC) of a 4*EPC deep slab):
+//   fp16: one v_mfma_f32_16x16x32_f16 (K = 32);  fp32: four v_mfma_f32_16x16x4_f32 (element s of every lane
+//   forms k-slab s; any k partition is valid as long as A and B use the same one).
+__device__ __forceinline__ void sr_mma(f32x4& acc, const uint4& a, const uint4& b, _Float16) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void sr_mma(f32x4& acc, const uint4& a, const uint4& b, float) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void sr_glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float sr_silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sr_gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float sr_load_f(const _Float16* p) { return (float)*p; }
+__device__ __forceinline__ float sr_load_f(const float* p) { return *p; }
+__device__ __forceinline__ void sr_store_f(_Float16* p, float v) { *p = (_Float16)v; }
+__device__ __forceinline__ void sr_store_f(float* p, float v) { *p = v; }
+
+// bijective XCD-aware remap of a linear workgroup id (blocks b and b+8 share an XCD; give each XCD a
+// contiguous chunk of the tile space so neighbouring tiles hit the same L2).
+__device__ __forceinline__ int sr_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+static inline hipStream_t sr_stream(void* s) { return (hipStream_t)s; }
+static inline int sr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,225 @@
+"""Thin torch-tensor wrappers over the C ABI (plumbing only: pointers, shapes, streams).  Every function
+launches HIP kernels from libsr_hip.so; nothing here computes on the CPU or through torch ops."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+DT = {torch.float16: L.SR_F16, torch.float32: L.SR_F32}
+TDT = {L.SR_F16: torch.float16, L.SR_F32: torch.float32}
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_zero_pages = {}
+
+
+def zero_page(device):
+    """64 KiB of zeros: source for padding taps / out-of-range rows of the implicit GEMM."""
+    key = str(device)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(65536, dtype=torch.uint8, device=device)
+    return _zero_pages[key]
+
+
+def kelems(dtype):
+    return 64 if dtype == torch.float16 else 32
+
+
+def pack_conv_weight(w, dtype, cin_pad=None, geglu=False):
+    """torch conv/linear weight [N, Cin, KH, KW] or [N, Cin] -> packed [Npad, KH*KW*Cin_pad] (K = (ky,kx,c)),
+    Npad multiple of 128 (zero rows), Cin padded with zero columns to the K-step.  GEGLU: rows interleaved
+    (value_i, gate_i) so the epilogue finds both halves in one lane."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    n, cin, kh, kw = w.shape
+    ke = kelems(dtype)
+    cp = cin_pad if cin_pad is not None else (cin + ke - 1) // ke * ke
+    if geglu:
+        half = n // 2
+        w = torch.stack([w[:half], w[half:]], dim=1).reshape(n, cin, kh, kw)
+    wp = torch.zeros((n + 127) // 128 * 128, kh, kw, cp, dtype=torch.float32)
+    wp[:n, :, :, :cin] = w.permute(0, 2, 3, 1).float()
+    return wp.reshape(wp.shape[0], kh * kw * cp).to(dtype).contiguous()
+
+
+def pack_bias(b, geglu=False):
+    b = b.float()
+    if geglu:
+        half = b.shape[0] // 2
+        b = torch.stack([b[:half], b[half:]], dim=1).reshape(-1)
+    return b.contiguous()
+
+
+def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C2=0, bias=None, rowvec=None,
+               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None):
+    ar = L.IgemmArgs()
+    ar.a, ar.a2, ar.w, ar.bias, ar.rowvec, ar.residual, ar.out = _p(a), _p(a2), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
+    ar.zero_page = _p(zero_page(a.device))
+    ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample = B, H, W, C1, C2, N, KH, stride, upsample
+    ar.act, ar.transpose_out, ar.ldt, ar.out_f32 = act, transpose_out, ldt, out_f32
+    ar.dtype = DT[a.dtype if dtype is None else dtype]
+    ar.scale = scale
+    return ar
+
+
+def igemm(*a, **k):
+    ar = igemm_args(*a, **k)
+    L.check(L.lib().sr_igemm(C.byref(ar), stream_ptr()))
+
+
+def groupnorm_args(x, gamma, beta, y, B, HW, C1, partials, x2=None, C2=0, groups=32, eps=1e-5, silu=False):
+    ar = L.GroupNormArgs()
+    ar.x, ar.x2, ar.gamma, ar.beta, ar.y, ar.partials = _p(x), _p(x2), _p(gamma), _p(beta), _p(y), _p(partials)
+    ar.B, ar.HW, ar.C1, ar.C2, ar.groups, ar.silu, ar.dtype, ar.eps = B, HW, C1, C2, groups, int(silu), DT[x.dtype], eps
+    return ar
+
+
+def groupnorm(x, gamma, beta, B, HW, C1, x2=None, C2=0, groups=32, eps=1e-5, silu=False):
+    y = torch.empty(B, HW, C1 + C2, dtype=x.dtype, device=x.device)
+    partials = torch.empty(L.lib().sr_groupnorm_scratch_floats(B, HW), dtype=torch.float32, device=x.device)
+    ar = groupnorm_args(x, gamma, beta, y, B, HW, C1, partials, x2, C2, groups, eps, silu)
+    L.check(L.lib().sr_groupnorm(C.byref(ar), stream_ptr()))
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x)
+    L.check(L.lib().sr_layernorm(_p(x), _p(gamma), _p(beta), _p(y), rows, Cc, eps, DT[x.dtype], stream_ptr()))
+    return y
+
+
+def attention_args(q, k, vt, o, B, Bk, Tq, Tk, heads, d, ldt, q_stride=None, k_stride=None, scale=None):
+    ar = L.AttentionArgs()
+    ar.q, ar.k, ar.vt, ar.o = _p(q), _p(k), _p(vt), _p(o)
+    ar.B, ar.Bk, ar.Tq, ar.Tk, ar.heads, ar.d, ar.ldt, ar.dtype = B, Bk, Tq, Tk, heads, d, ldt, DT[q.dtype]
+    ar.q_stride = heads * d if q_stride is None else q_stride
+    ar.k_stride = heads * d if k_stride is None else k_stride
+    ar.scale = d ** -0.5 if scale is None else scale
+    return ar
+
+
+def attention(q, k, vt, heads, Tk=None):
+    """q [B,Tq,C], k [Bk,Tk,C], vt [Bk,heads,d,ldt] -> o [B,Tq,C]"""
+    B, Tq, Cc = q.shape
+    Bk = k.shape[0]
+    Tk = k.shape[1] if Tk is None else Tk
+    d = Cc // heads
+    o = torch.empty_like(q)
+    ar = attention_args(q, k, vt, o, B, Bk, Tq, Tk, heads, d, vt.shape[-1])
+    L.check(L.lib().sr_attention(C.byref(ar), stream_ptr()))
+    return o
+
+
+def nchw_to_nhwc(x, dtype, cpad=None, scale=1.0, per_batch_scale=None):
+    B, Cc, H, W = x.shape
+    cpad = Cc if cpad is None else cpad
+    y = torch.empty(B, H * W, cpad, dtype=dtype, device=x.device)
+    L.check(L.lib().sr_nchw_to_nhwc(_p(x), _p(y), B, Cc, H * W, cpad, scale, _p(per_batch_scale), DT[dtype], stream_ptr()))
+    return y
+
+
+def nhwc_to_nchw(x, B, Cc, H, W, ldc=None):
+    y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    L.check(L.lib().sr_nhwc_to_nchw(_p(x), _p(y), B, Cc, H * W, Cc if ldc is None else ldc, DT[x.dtype], stream_ptr()))
+    return y
+
+
+def timestep_embedding(t, dim, dtype):
+    y = torch.empty(t.shape[0], dim, dtype=dtype, device=t.device)
+    L.check(L.lib().sr_timestep_embedding(_p(t), _p(y), t.shape[0], dim, DT[dtype], stream_ptr()))
+    return y
+
+
+# ---- stable-rendering kernels -----------------------------------------------------------------------
+def idmap_masks(ids):
+    m = torch.empty(ids.shape[:-1], dtype=torch.float32, device=ids.device)
+    L.check(L.lib().sr_idmap_masks(_p(ids), _p(m), m.numel(), stream_ptr()))
+    return m
+
+
+class OverlapIndex:
+    """Per-call overlap structure (sr_overlap_build): replaces create_vertex_screen_info + per-step unique()."""
+
+    def __init__(self, ids, lh, lw):
+        assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.dim() == 4 and ids.shape[-1] == 4
+        self.ids = ids
+        self.N, self.H, self.W = ids.shape[:3]
+        self.lh, self.lw = lh, lw
+        dev = ids.device
+        self.pix_cell = torch.empty(self.N * self.H * self.W, dtype=torch.int32, device=dev)
+        self.cell_vid = torch.empty(self.N * lh * lw, dtype=torch.int32, device=dev)
+        info = torch.zeros(4, dtype=torch.int32, device=dev)
+        L.check(L.lib().sr_overlap_build(_p(ids), self.N, self.H, self.W, lh, lw, _p(self.pix_cell), _p(self.cell_vid),
+                                         _p(info), stream_ptr()))
+        max_vid, oob, nvalid, _ = info.tolist()         # one host sync per sampling call (not per step)
+        if oob:
+            # the reference's advanced indexing raises for these (corresponder.py:321-330)
+            raise IndexError("id-map pixel maps outside the latent (non-square frame?): index out of bounds")
+        self.n_valid = nvalid
+        self.cap = max_vid + 1
+        self.vsum = None
+
+    def step(self, x, ratio, blended_out=None):
+        """in-place OverlapCorresponder.step_finished body on x (N,C,lh,lw) fp32 contiguous"""
+        assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[2:]) == (self.lh, self.lw)
+        Cc = x.shape[1]
+        if self.vsum is None or self.vsum.numel() < self.cap * (Cc + 1):
+            self.vsum = torch.empty(self.cap * (Cc + 1), dtype=torch.float32, device=x.device)
+        L.check(L.lib().sr_overlap_step(_p(x), _p(self.ids), _p(self.pix_cell), _p(self.cell_vid), self.N, Cc, self.H,
+                                        self.W, self.lh, self.lw, self.cap, float(ratio), _p(self.vsum), _p(blended_out),
+                                        None, stream_ptr()))
+        return x
+
+
+def adain_nchw(content, style, eps=1e-5):
+    """content (N,C,h,w) fp32, style (N,C,H,W) fp32|fp16 -> (N,C,h,w) fp32"""
+    N, Cc = content.shape[:2]
+    hwc, hws = content[0, 0].numel(), style[0, 0].numel()
+    content, style = content.contiguous(), style.contiguous()
+    out = torch.empty_like(content, dtype=torch.float32)
+    L.check(L.lib().sr_adain(_p(content), 1, hwc, Cc * hwc, hwc, _p(style), DT[style.dtype], 1, hws, Cc * hws, hws,
+                             _p(out), N, Cc, eps, None, stream_ptr()))
+    return out
+
+
+def noise_pool(noise_f16, alpha_f16, bg_f32):
+    """(1,H,W,4) fp16, (1,H,W) fp16, (1,H,W,4) fp32 -> pooled (H/8,W/8,4) fp32, latent noise (1,4,H/8,W/8)"""
+    H, W = noise_f16.shape[1:3]
+    pooled = torch.empty(H // 8, W // 8, 4, dtype=torch.float32, device=noise_f16.device)
+    out = torch.empty(1, 4, H // 8, W // 8, dtype=torch.float32, device=noise_f16.device)
+    L.check(L.lib().sr_noise_pool(_p(noise_f16), _p(alpha_f16), _p(bg_f32), _p(pooled), _p(out), H, W, None, stream_ptr()))
+    return pooled, out
+
+
+# ---- sampler arithmetic -------------------------------------------------------------------------------
+def eps_scale_input(x, xin, copies, sigma):
+    L.check(L.lib().sr_eps_scale_input(_p(x), _p(xin), x.numel(), copies, float(sigma), stream_ptr()))
+
+
+def cfg_denoise(x, eps, den, d, copies, sigma, cfg):
+    L.check(L.lib().sr_cfg_denoise(_p(x), _p(eps), _p(den), _p(d), x.numel(), copies, float(sigma), float(cfg), stream_ptr()))
+
+
+def euler_step(x, d, dt):
+    L.check(L.lib().sr_euler_step(_p(x), _p(d), x.numel(), float(dt), stream_ptr()))
+
+
+def ddpm_step(x, den, noise, sigma, sigma_next):
+    L.check(L.lib().sr_ddpm_step(_p(x), _p(den), _p(noise), x.numel(), float(sigma), float(sigma_next), stream_ptr()))
+
+
+def lcm_step(x, den, noise, sigma_next):
+    L.check(L.lib().sr_lcm_step(_p(x), _p(den), _p(noise), x.numel(), float(sigma_next), stream_ptr()))
+
+
+def axpby(y, x, a, b):
+    L.check(L.lib().sr_axpby(_p(y), _p(x), x.numel(), float(a), float(b), stream_ptr()))

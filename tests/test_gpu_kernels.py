@@ -1,0 +1,328 @@
+"""GPU parity tests of the individual HIP kernels through the C ABI.  Floating-point kernels are compared with a
+plain torch fp32 reference of the same op (tolerance stated per test); index/integer kernels with the oracle,
+bit exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from stable_renderer_amd import ops as o
+    return o
+
+
+def rnd(seed, *shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def tol(dtype):
+    # fp16 path: fp16 operands, fp32 accumulate -> relative error ~ 2^-11 * sqrt(K) growth; fp32 path ~1e-5
+    return (3e-2, 2e-2) if dtype == torch.float16 else (2e-4, 2e-4)
+
+
+def close(a, b, dtype, scale=1.0):
+    atol, rtol = tol(dtype)
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    lim = atol * scale + rtol * b.abs()
+    assert bool((err <= lim).all()), f"max err {err.max().item():.4g} (ref max {b.abs().max().item():.4g})"
+
+
+DTYPES = [torch.float16, torch.float32]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["linear_small", "linear_big", "conv3", "conv3_stride2", "conv3_up", "conv3_cat",
+                                  "conv_cin4", "conv_n4", "geglu", "residual_rowvec", "transposed", "transposed_77"])
+def test_igemm(ops, dtype, case):
+    dev = "cuda"
+    ke = ops.kelems(dtype)
+    B, H, W, C1, C2, N, KH, stride, up, act = 2, 8, 8, 2 * ke, 0, 96, 1, 1, 0, 0
+    trans = False
+    if case == "linear_small":
+        B, H, W, N = 3, 1, 1, 200                          # time-embedding sized GEMM (M=3)
+    elif case == "linear_big":
+        B, H, W, C1, N = 2, 40, 36, 5 * ke, 320            # M=2880 -> 128x64 / 128x128 tiles, N=320
+    elif case == "conv3":
+        KH, N = 3, 128
+    elif case == "conv3_stride2":
+        KH, stride, H, W = 3, 2, 10, 12
+    elif case == "conv3_up":
+        KH, up, H, W = 3, 1, 6, 5
+    elif case == "conv3_cat":
+        KH, C2, N = 3, ke, 64
+    elif case == "conv_cin4":
+        KH, C1, N, H, W = 3, 4, 64, 16, 16                  # conv_in: 4 channels zero-padded to one K-step
+    elif case == "conv_n4":
+        KH, N, H, W = 3, 4, 16, 16                          # conv_out: 4 valid output channels
+    elif case == "geglu":
+        N, act = 256, 2
+    elif case == "residual_rowvec":
+        KH, N = 3, 160
+    elif case == "transposed":
+        trans, B, H, W, N = True, 2, 8, 8, 80
+    elif case == "transposed_77":
+        trans, B, H, W, N = True, 2, 77, 1, 80              # cross-attention V^T from the 77-token context
+
+    cin = C1 + C2
+    x = rnd(1, B, cin, H, W)
+    w = rnd(2, N, cin, KH, KH) * (cin * KH * KH) ** -0.5
+    bias = rnd(3, N) * 0.1
+    # reference (fp32, on the dtype-rounded operands)
+    xr, wr = x.to(dtype).float(), w.to(dtype).float()
+    xi = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    ref = F.conv2d(xi, wr, bias, stride=stride, padding=KH // 2)
+    Ho, Wo = ref.shape[2:]
+    rowvec = resid = None
+    if case == "residual_rowvec":
+        rowvec = rnd(4, B, N)
+        resid = rnd(5, B, N, Ho, Wo)
+        ref = ref + rowvec[:, :, None, None] + resid.to(dtype).float()
+    if act == 2:
+        a, g = ref.chunk(2, dim=1)
+        ref = a * F.gelu(g)
+    # device inputs (NHWC, channel padded)
+    c1p = (C1 + ke - 1) // ke * ke
+    xa = torch.zeros(B, H, W, c1p, dtype=dtype)
+    xa[..., :C1] = x[:, :C1].permute(0, 2, 3, 1).to(dtype)
+    xa = xa.to(dev)
+    xb = x[:, C1:].permute(0, 2, 3, 1).contiguous().to(dtype).to(dev) if C2 else None
+    if C2:
+        wp = ops.pack_conv_weight(w, dtype)
+    else:
+        wp = ops.pack_conv_weight(w, dtype, cin_pad=c1p, geglu=(act == 2))
+    wp = wp.to(dev)
+    bp = ops.pack_bias(bias, geglu=(act == 2)).to(dev)
+    nout = N // 2 if act == 2 else N
+    M = B * Ho * Wo
+    if trans:
+        ldt = (Ho * Wo + 7) // 8 * 8
+        out = torch.zeros(B, N, ldt, dtype=dtype, device=dev)
+        ops.igemm(xa, wp, out, B, H, W, c1p, N, KH=KH, stride=stride, upsample=up, bias=bp, transpose_out=1, ldt=ldt)
+        torch.cuda.synchronize()
+        got = out[:, :, :Ho * Wo].float().cpu()
+        close(got, ref.reshape(B, N, Ho * Wo), dtype, scale=ref.abs().max().item())
+        assert float(out[:, :, Ho * Wo:].abs().max().item() if ldt > Ho * Wo else 0.0) == 0.0
+        return
+    out = torch.zeros(M, nout, dtype=dtype, device=dev)
+    rv = rowvec.to(dev) if rowvec is not None else None
+    rs = resid.permute(0, 2, 3, 1).reshape(M, N).contiguous().to(dtype).to(dev) if resid is not None else None
+    ops.igemm(xa, wp, out, B, H, W, c1p, N, KH=KH, stride=stride, upsample=up, a2=xb, C2=C2, bias=bp, rowvec=rv,
+              residual=rs, act=act)
+    torch.cuda.synchronize()
+    got = out.float().cpu().reshape(B, Ho, Wo, nout).permute(0, 3, 1, 2)
+    close(got, ref, dtype, scale=ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_igemm_out_f32_and_scale(ops, dtype):
+    ke = ops.kelems(dtype)
+    B, T, Cc, N = 2, 50, 2 * ke, 72
+    x = rnd(1, B * T, Cc)
+    w = rnd(2, N, Cc) * Cc ** -0.5
+    out = torch.zeros(B * T, N, dtype=torch.float32, device="cuda")
+    ops.igemm(x.to(dtype).cuda(), ops.pack_conv_weight(w, dtype).cuda(), out, B * T, 1, 1, Cc, N, out_f32=1, scale=0.5)
+    torch.cuda.synchronize()
+    ref = 0.5 * (x.to(dtype).float() @ w.to(dtype).float().t())
+    close(out, ref, torch.float32 if dtype == torch.float32 else torch.float16, scale=ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 70, 320, 0, True), (1, 256, 64, 64, False), (2, 33, 2560, 0, True), (1, 4096, 128, 0, True)])
+def test_groupnorm(ops, dtype, cfg):
+    B, HW, C1, C2, silu = cfg
+    x = rnd(1, B, HW, C1 + C2) * 1.5 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(2, C1 + C2), 0.1 * rnd(3, C1 + C2)
+    xd = x.to(dtype)
+    ref = F.group_norm(xd.float().permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    x1 = xd[..., :C1].contiguous().cuda()
+    x2 = xd[..., C1:].contiguous().cuda() if C2 else None
+    y = ops.groupnorm(x1, gamma.cuda(), beta.cuda(), B, HW, C1, x2=x2, C2=C2, eps=1e-5, silu=silu)
+    torch.cuda.synchronize()
+    a, r = (4e-3, 4e-3) if dtype == torch.float16 else (1e-5, 1e-5)
+    assert torch.allclose(y.float().cpu(), ref, atol=a, rtol=r), (y.float().cpu() - ref).abs().max()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cc", [64, 320, 1280])
+def test_layernorm(ops, dtype, Cc):
+    x = rnd(1, 3, 37, Cc) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * rnd(2, Cc), 0.1 * rnd(3, Cc)
+    xd = x.to(dtype)
+    ref = F.layer_norm(xd.float(), (Cc,), gamma, beta, 1e-5)
+    y = ops.layernorm(xd.cuda(), gamma.cuda(), beta.cuda())
+    torch.cuda.synchronize()
+    a, r = (4e-3, 4e-3) if dtype == torch.float16 else (1e-5, 1e-5)
+    assert torch.allclose(y.float().cpu(), ref, atol=a, rtol=r)
+
+
+def _attn_ref(q, k, v, heads):
+    B, Tq, Cc = q.shape
+    d = Cc // heads
+    qh = q.view(B, Tq, heads, d).transpose(1, 2)
+    kh = k.view(k.shape[0], -1, heads, d).transpose(1, 2)
+    vh = v.view(v.shape[0], -1, heads, d).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * d ** -0.5
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Tq, Cc)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    # B, Bk, Tq, Tk, heads, d
+    (2, 2, 256, 256, 8, 40),      # SD1.5 64x64-level shape class (d=40)
+    (2, 2, 100, 77, 8, 40),       # cross attention: ragged Tq, 77 keys (masked tail)
+    (3, 1, 128, 192, 8, 40),      # shared K/V (OverlapCorresponder injection)
+    (1, 1, 64, 64, 8, 80),
+    (1, 1, 64, 130, 8, 160),
+    (2, 2, 96, 64, 8, 8),
+    (1, 1, 80, 64, 4, 16),
+    (1, 1, 80, 70, 2, 32),
+    (1, 1, 64, 64, 2, 64),
+])
+def test_attention(ops, dtype, cfg):
+    B, Bk, Tq, Tk, heads, d = cfg
+    Cc = heads * d
+    q, k, v = rnd(1, B, Tq, Cc), rnd(2, Bk, Tk, Cc), rnd(3, Bk, Tk, Cc)
+    qd, kd, vd = q.to(dtype), k.to(dtype), v.to(dtype)
+    ref = _attn_ref(qd.float(), kd.float().expand(B, -1, -1) if Bk == 1 else kd.float(),
+                    vd.float().expand(B, -1, -1) if Bk == 1 else vd.float(), heads)
+    ldt = (Tk + 7) // 8 * 8
+    vt = torch.zeros(Bk, heads, d, ldt, dtype=dtype)
+    vt[..., :Tk] = vd.view(Bk, Tk, heads, d).permute(0, 2, 3, 1)
+    o = ops.attention(qd.cuda(), kd.cuda(), vt.cuda(), heads, Tk=Tk)
+    torch.cuda.synchronize()
+    a, r = (6e-3, 2e-2) if dtype == torch.float16 else (2e-5, 1e-4)
+    err = (o.float().cpu() - ref).abs().max().item()
+    assert torch.allclose(o.float().cpu(), ref, atol=a, rtol=r), err
+
+
+def test_attention_softmax_spike(ops):
+    """online-softmax rescale path: one key dominates late in the sequence (rule: force the rare branch)."""
+    dtype = torch.float32
+    B, T, heads, d = 1, 256, 8, 40
+    q, k, v = rnd(1, B, T, heads * d), rnd(2, B, T, heads * d), rnd(3, B, T, heads * d)
+    k[:, 200] = q[:, 17] * 6.0
+    ref = _attn_ref(q, k, v, heads)
+    vt = v.view(B, T, heads, d).permute(0, 2, 3, 1).contiguous()
+    o = ops.attention(q.cuda(), k.cuda(), vt.cuda(), heads)
+    assert torch.allclose(o.cpu(), ref, atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_and_embedding(ops, dtype):
+    x = rnd(1, 2, 4, 6, 5)
+    pbs = torch.tensor([0.5, 2.0])
+    y = ops.nchw_to_nhwc(x.cuda(), dtype, cpad=8, scale=3.0, per_batch_scale=pbs.cuda())
+    ref = torch.zeros(2, 30, 8)
+    ref[..., :4] = (x * 3.0 * pbs[:, None, None, None]).permute(0, 2, 3, 1).reshape(2, 30, 4)
+    assert torch.allclose(y.float().cpu(), ref.to(dtype).float(), atol=1e-6)
+    back = ops.nhwc_to_nchw(y, 2, 4, 6, 5, ldc=8)
+    assert torch.allclose(back.cpu(), ref[..., :4].to(dtype).float().reshape(2, 6, 5, 4).permute(0, 3, 1, 2))
+    import sr_oracle as O
+    t = torch.tensor([0.0, 17.0, 500.0, 999.0])
+    e = ops.timestep_embedding(t.cuda(), 320, dtype)
+    a = 2e-3 if dtype == torch.float16 else 2e-4      # GPU sinf/cosf of arguments up to ~1e3
+    assert torch.allclose(e.float().cpu(), O.timestep_embedding(t, 320), atol=a)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_idmap_masks_and_overlap_vs_oracle_and_golden(ops):
+    import sr_oracle as O
+    d = np.load(os.path.join(GOLD, "overlap_step.npz"))
+    meta = json.loads(bytes(d["meta"]).decode())
+    for name, m in meta.items():
+        ids = torch.from_numpy(d[f"{name}_ids"]).cuda()
+        x = torch.from_numpy(d[f"{name}_x"])
+        assert np.array_equal(ops.idmap_masks(ids).cpu().numpy(), O.idmap_masks(d[f"{name}_ids"]))   # bit exact
+        if m["timestep"] < m["stop"]:
+            continue
+        idx = ops.OverlapIndex(ids, x.shape[2], x.shape[3])
+        # integer structure: bit exact against the oracle's vertex_screen_info
+        vsi = O.vertex_screen_info(d[f"{name}_ids"])
+        assert idx.n_valid == len(vsi)
+        n, c, h, w = x.shape
+        sx = (vsi[:, 4] * np.float32(w)).astype(np.int32)
+        sy = (vsi[:, 5] * np.float32(h)).astype(np.int32)
+        cell = (vsi[:, 6].astype(np.int32) * h + sy) * w + sx
+        exp_vid = np.full(n * h * w, -1, np.int32)
+        exp_vid[cell] = vsi[:, 3].astype(np.int32)               # sequential: last row wins
+        assert np.array_equal(idx.cell_vid.cpu().numpy(), exp_vid), name
+        xg = x.clone().cuda()
+        idx.step(xg, m["ratio"])
+        out = xg.cpu()
+        ref = torch.from_numpy(d[f"{name}_out"])                 # the reference's own output
+        assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5), (name, (out - ref).abs().max())
+        assert torch.allclose(out, O.overlap_step(x, d[f"{name}_ids"], m["ratio"]), atol=1e-5, rtol=1e-5)
+
+
+def test_overlap_nonsquare_raises(ops):
+    ids = torch.ones(1, 48, 32, 4, dtype=torch.int32).cuda()
+    with pytest.raises(IndexError):
+        ops.OverlapIndex(ids, 6, 4)
+
+
+def test_adain_and_noise_pool_vs_golden(ops):
+    d = np.load(os.path.join(GOLD, "adain.npz"))
+    for s in range(2):
+        o = ops.adain_nchw(torch.from_numpy(d[f"nchw_c{s}"]).cuda(), torch.from_numpy(d[f"nchw_s{s}"]).cuda())
+        assert torch.allclose(o.cpu(), torch.from_numpy(d[f"nchw_o{s}"]), atol=2e-6, rtol=1e-5)
+    d = np.load(os.path.join(GOLD, "noise_pool.npz"))
+    for i in range(2):
+        pooled, out = ops.noise_pool(torch.from_numpy(d[f"n{i}_noise"]).cuda(), torch.from_numpy(d[f"n{i}_alpha"]).cuda(),
+                                     torch.from_numpy(d[f"n{i}_bg"]).cuda())
+        assert torch.allclose(pooled.cpu(), torch.from_numpy(d[f"n{i}_pooled"]), atol=1e-6, rtol=1e-6)
+        # style statistics are fp16-rounded in the reference: one fp16 ulp of std/mean = 1e-3 relative
+        assert torch.allclose(out.cpu(), torch.from_numpy(d[f"n{i}_out"]), atol=3e-3, rtol=2e-3)
+
+
+def test_sampler_math(ops):
+    import sr_oracle as O
+    x = rnd(1, 3, 4, 8, 8).cuda()
+    n = x.numel()
+    xin = torch.empty(2 * n, device="cuda")
+    ops.eps_scale_input(x, xin, 2, 3.0)
+    ref = O.eps_input(x.cpu(), torch.full((3,), 3.0))
+    assert torch.allclose(xin[:n].cpu().view_as(ref), ref, rtol=1e-6) and torch.equal(xin[:n], xin[n:])
+    eps = rnd(2, 2 * n).cuda()
+    den, dd = torch.empty_like(x), torch.empty_like(x)
+    ops.cfg_denoise(x, eps, den, dd, 2, 3.0, 7.5)
+    xc = x.cpu().reshape(-1)
+    u, c = xc - eps[:n].cpu() * 3.0, xc - eps[n:].cpu() * 3.0
+    rden = u + (c - u) * 7.5
+    assert torch.allclose(den.cpu().reshape(-1), rden, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(dd.cpu().reshape(-1), (xc - rden) / 3.0, rtol=1e-5, atol=1e-5)
+    # ddpm / euler / lcm single steps against the oracle loop with a frozen "model"
+    sig = torch.tensor([3.0, 1.2, 0.0])
+    for sampler in ("euler", "ddpm", "lcm"):
+        x0 = rnd(5, 2, 4, 8, 8)
+        fixed_den = rnd(6, 2, 4, 8, 8) * 0.3
+        torch.manual_seed(9)
+        ref = O.sample_loop(lambda xx, s: fixed_den, x0.clone(), sig, sampler)
+        torch.manual_seed(9)
+        xg, dg = x0.clone().cuda(), fixed_den.cuda()
+        for i in range(2):
+            s, sn = float(sig[i]), float(sig[i + 1])
+            if sampler == "euler":
+                dd = (xg - dg) / s
+                ops.euler_step(xg, dd, sn - s)
+            elif sampler == "ddpm":
+                nz = torch.randn_like(x0).cuda() if sn > 0 else None
+                ops.ddpm_step(xg, dg, nz, s, sn)
+            else:
+                nz = torch.randn_like(x0).cuda() if sn > 0 else None
+                ops.lcm_step(xg, dg, nz, sn)
+        assert torch.allclose(xg.cpu(), ref, atol=2e-5, rtol=1e-5), sampler
