@@ -55,7 +55,8 @@ typedef struct {
   int32_t KH;             /* 1 or 3 (square kernel, pad = KH/2)                                        */
   int32_t stride;         /* 1 or 2                                                                    */
   int32_t upsample;       /* 1: nearest x2 upsample fused in front of the conv (Upsample, :82-119)     */
-  int32_t act;            /* 0 none, 1 SiLU, 2 GEGLU (pairs (value,gate) interleaved along n), 3 GELU  */
+  int32_t act;            /* 0 none, 1 SiLU, 2 GEGLU ((value,gate) pairs interleaved along n), 3 GELU,
+                             4 clamp((v+1)/2, 0, 1) (VAE.decode image range, sd.py:335)                */
   int32_t transpose_out;  /* 1: write out[b][n][t] (t = pixel in batch, row stride ldt) — V^T for attn */
   int32_t ldt;            /* row stride of the transposed output (>= pixels per batch)                 */
   int32_t out_f32;        /* 1: store fp32 regardless of dtype                                         */

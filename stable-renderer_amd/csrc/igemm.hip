@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sr_igemm_args p, const
         if (p.rowvec) { for (int r = 0; r < nv; ++r) v[r] += p.rowvec[(int64_t)b * N + n + r]; }
         if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
         else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
+        else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
         if (p.act == 2) {                                // GEGLU: (value, gate) pairs interleaved along n
           float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
           const int64_t oi = (int64_t)m * ldo + (n >> 1);

@@ -1,0 +1,128 @@
+"""Launch plans: a model forward lowered once to a flat array of C-ABI ops (include/sr_hip.h: sr_op) over
+pre-allocated HBM buffers, then replayed natively (eagerly or as a hipGraph) every denoise step."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops as O
+
+
+class Plan:
+    def __init__(self, op_list, keep):
+        self.n = len(op_list)
+        self.ops = (L.Op * max(self.n, 1))(*op_list)
+        self._keep = keep                      # tensors referenced by raw pointers inside the ops
+        self._graph = None
+        self._graph_stream = None
+
+    def run(self):
+        L.check(L.lib().sr_plan_run(self.ops, self.n, O.stream_ptr()))
+
+    def capture(self, stream):
+        """capture into a hipGraph on `stream` (a torch.cuda.Stream, not the default one)"""
+        ge = C.c_void_p()
+        L.check(L.lib().sr_plan_capture(self.ops, self.n, C.c_void_p(stream.cuda_stream), C.byref(ge)))
+        self._graph, self._graph_stream = ge, stream
+
+    def launch(self):
+        if self._graph is None:
+            return self.run()
+        L.check(L.lib().sr_graph_launch(self._graph, O.stream_ptr()))
+
+    def __del__(self):
+        try:
+            if self._graph is not None:
+                L.lib().sr_graph_destroy(self._graph)
+        except Exception:
+            pass
+
+
+class PlanBuilder:
+    """Collects ops + owns the activation buffers they point at."""
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype = device, dtype
+        self.ops = []
+        self.keep = []
+        self._gn_scratch = None
+        self.flops = 0
+
+    def buf(self, *shape, dtype=None, zero=False):
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype or self.dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def hold(self, *ts):
+        self.keep.extend(t for t in ts if t is not None)
+
+    def _emit(self, kind, field, args):
+        op = L.Op()
+        op.kind = kind
+        setattr(op.u, field, args)
+        self.ops.append(op)
+
+    # ---- ops ------------------------------------------------------------------------------------------
+    def igemm(self, a, w, out, B, H, W, C1, N, **kw):
+        self.hold(a, w, out, kw.get("a2"), kw.get("bias"), kw.get("rowvec"), kw.get("residual"))
+        self._emit(L.OP_IGEMM, "igemm", O.igemm_args(a, w, out, B, H, W, C1, N, dtype=self.dtype, **kw))
+        KH, st, up = kw.get("KH", 1), kw.get("stride", 1), kw.get("upsample", 0)
+        Ho, Wo = (2 * H, 2 * W) if up else ((H + st - 1) // st, (W + st - 1) // st)
+        self.flops += 2 * B * Ho * Wo * N * KH * KH * (C1 + kw.get("C2", 0))
+
+    def groupnorm(self, x, gamma, beta, y, B, HW, C1, x2=None, C2=0, eps=1e-5, silu=False):
+        need = L.lib().sr_groupnorm_scratch_floats(B, HW)
+        if self._gn_scratch is None or self._gn_scratch.numel() < need:
+            self._gn_scratch = self.buf(need, dtype=torch.float32)
+        self.hold(x, x2, gamma, beta, y)
+        self._emit(L.OP_GROUPNORM, "gn", O.groupnorm_args(x, gamma, beta, y, B, HW, C1, self._gn_scratch, x2, C2, 32, eps, silu))
+
+    def layernorm(self, x, gamma, beta, y, rows, Cc, eps=1e-5):
+        self.hold(x, gamma, beta, y)
+        a = L._Ln()
+        a.x, a.gamma, a.beta, a.y = O._p(x), O._p(gamma), O._p(beta), O._p(y)
+        a.rows, a.C, a.dtype, a.eps = rows, Cc, O.DT[self.dtype], eps
+        self._emit(L.OP_LAYERNORM, "ln", a)
+
+    def attention(self, q, k, vt, o, B, Bk, Tq, Tk, heads, d, ldt):
+        self.hold(q, k, vt, o)
+        self._emit(L.OP_ATTENTION, "attn", O.attention_args(q, k, vt, o, B, Bk, Tq, Tk, heads, d, ldt))
+        self.flops += 4 * B * heads * Tq * Tk * d
+
+    def nchw_to_nhwc(self, x, y, B, Cc, HW, Cpad, scale=1.0):
+        self.hold(x, y)
+        a = L._Cvt()
+        a.x, a.y, a.per_batch_scale = O._p(x), O._p(y), None
+        a.B, a.C, a.HW, a.Cpad, a.dtype, a.ldc, a.scale = B, Cc, HW, Cpad, O.DT[y.dtype], Cpad, scale
+        self._emit(L.OP_NCHW_TO_NHWC, "cvt", a)
+
+    def nhwc_to_nchw(self, x, y, B, Cc, HW, ldc):
+        self.hold(x, y)
+        a = L._Cvt()
+        a.x, a.y, a.per_batch_scale = O._p(x), O._p(y), None
+        a.B, a.C, a.HW, a.Cpad, a.dtype, a.ldc, a.scale = B, Cc, HW, ldc, O.DT[x.dtype], ldc, 1.0
+        self._emit(L.OP_NHWC_TO_NCHW, "cvt", a)
+
+    def timestep_embedding(self, t, y, B, dim):
+        self.hold(t, y)
+        a = L._Temb()
+        a.t, a.y, a.B, a.dim, a.dtype = O._p(t), O._p(y), B, dim, O.DT[y.dtype]
+        self._emit(L.OP_TIMESTEP_EMBED, "temb", a)
+
+    def silu(self, x, y):
+        self.hold(x, y)
+        a = L._Ew()
+        a.x, a.y, a.n, a.dtype = O._p(x), O._p(y), x.numel(), O.DT[x.dtype]
+        self._emit(L.OP_SILU, "ew", a)
+
+    def softmax_rows(self, x, rows, cols):
+        self.hold(x)
+        a = L._Ew()
+        a.x, a.y, a.n, a.dtype, a.rows, a.cols = O._p(x), O._p(x), x.numel(), O.DT[x.dtype], rows, cols
+        self._emit(L.OP_SOFTMAX_ROWS, "ew", a)
+
+    def take(self):
+        """-> Plan of the ops emitted so far (the builder keeps collecting into a fresh list)"""
+        p = Plan(self.ops, list(self.keep))
+        self.ops = []
+        return p

@@ -1,0 +1,221 @@
+"""SD-family UNet lowered onto the HIP launch plan.
+
+Mirrors ``UNetModel.forward`` (comfyUI/comfy/ldm/modules/diffusionmodules/openaimodel.py:841-946),
+``ResBlock._forward`` (:253-281), ``Upsample/Downsample`` (:82-148), ``SpatialTransformer.forward`` and
+``BasicTransformerBlock._forward`` (comfy/ldm/modules/attention.py:495-726) including the call site of
+``corresponder.pre_atten_inject`` (attention.py:583-589).  The module tree is only walked at plan-build time; the
+per-step path is ``Plan.launch()`` (native).  Checkpoint keys are the reference's (``input_blocks.1.0.in_layers.0.weight``
+...), so a real SD1.5 state dict loads unchanged.
+
+MI355X layout decisions: activations NHWC so every conv / linear is one K-contiguous implicit GEMM
+(``b c h w <-> b (h w) c`` rearranges vanish); GroupNorm+SiLU is one streaming pass that also consumes the decoder's
+channel concat without materialising it; time-embedding add, bias, residual and GEGLU are GEMM epilogues; V is
+written transposed by its projection so attention needs no transpose; cross-attention K/V depend only on the prompt and
+are projected once per sampling run (prologue plan), not once per step.
+"""
+import torch
+
+from . import ops as O
+from .plan import PlanBuilder
+
+SD15_CFG = dict(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=[2, 2, 2, 2],
+                channel_mult=[1, 2, 4, 4], transformer_depth=[1, 1, 1, 1, 1, 1, 0, 0], transformer_depth_middle=1,
+                transformer_depth_output=[1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0], context_dim=768, num_heads=8)
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+class UNet:
+    def __init__(self, state_dict, cfg=None, dtype=torch.float16, device="cuda"):
+        self.cfg = dict(SD15_CFG if cfg is None else cfg)
+        self.dtype, self.device = dtype, torch.device(device)
+        self.ke = O.kelems(dtype)
+        self.w = {}
+        sd = state_dict
+        for k, v in sd.items():
+            if not k.endswith(".weight"):
+                continue
+            base = k[:-7]
+            b = sd.get(base + ".bias")
+            if v.dim() >= 2:
+                geglu = base.endswith("ff.net.0.proj")
+                cin_pad = None
+                if base == "input_blocks.0.0":
+                    cin_pad = _cdiv(v.shape[1], self.ke) * self.ke
+                self.w[base] = O.pack_conv_weight(v, dtype, cin_pad=cin_pad, geglu=geglu).to(self.device)
+                if b is not None:
+                    self.w[base + ".b"] = O.pack_bias(b, geglu=geglu).to(self.device)
+            else:                                                   # norm scale/shift stay fp32
+                self.w[base + ".g"] = v.float().contiguous().to(self.device)
+                self.w[base + ".beta"] = b.float().contiguous().to(self.device)
+        self.shapes = {k[:-7]: tuple(v.shape) for k, v in sd.items() if k.endswith(".weight")}
+
+    # ------------------------------------------------------------------------------------------------
+    def build(self, B, h, w, inject_idx=None, n_ctx=77):
+        """-> dict(prologue=Plan, step=Plan, x=(B,4,h,w) fp32 input buffer, t=(B,) fp32, ctx=(B,n_ctx,ctx_dim),
+        out=(B,4,h,w) fp32).  inject_idx: list of batch indices whose post-LayerNorm tokens every batch entry
+        attends to in self-attention (OverlapCorresponder.pre_atten_inject) or None."""
+        cfg, dt, dev = self.cfg, self.dtype, self.device
+        pb = PlanBuilder(dev, dt)
+        pro = PlanBuilder(dev, dt)                     # prompt-only work (cross-attention K/V)
+        W = self.w
+        mc, heads = cfg["model_channels"], cfg["num_heads"]
+        x_in = pb.buf(B, cfg["in_channels"], h, w, dtype=torch.float32, zero=True)
+        t_in = pb.buf(B, dtype=torch.float32, zero=True)
+        ctx = pb.buf(B, n_ctx, cfg["context_dim"], zero=True)
+        ldt_ctx = _cdiv(n_ctx, 8) * 8
+
+        # ---- time embedding ------------------------------------------------------------------------
+        temb = pb.buf(B, mc)
+        pb.timestep_embedding(t_in, temb, B, mc)
+        e1 = pb.buf(B, 4 * mc)
+        pb.igemm(temb, W["time_embed.0"], e1, B, 1, 1, mc, 4 * mc, bias=W["time_embed.0.b"], act=1)
+        e2 = pb.buf(B, 4 * mc)
+        pb.igemm(e1, W["time_embed.2"], e2, B, 1, 1, 4 * mc, 4 * mc, bias=W["time_embed.2.b"])
+        emb_s = pb.buf(B, 4 * mc)
+        pb.silu(e2, emb_s)                             # every ResBlock applies SiLU first (emb_layers.0)
+
+        def resblock(p, x1, C1, x2, C2, Cout, HW, hh, ww):
+            cin = C1 + C2
+            er = pb.buf(B, Cout, dtype=torch.float32)
+            pb.igemm(emb_s, W[p + ".emb_layers.1"], er, B, 1, 1, 4 * mc, Cout, bias=W[p + ".emb_layers.1.b"], out_f32=1)
+            n1 = pb.buf(B, HW, cin)
+            pb.groupnorm(x1, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.beta"], n1, B, HW, C1, x2=x2, C2=C2, eps=1e-5, silu=True)
+            hmid = pb.buf(B, HW, Cout)
+            pb.igemm(n1, W[p + ".in_layers.2"], hmid, B, hh, ww, cin, Cout, KH=3, bias=W[p + ".in_layers.2.b"], rowvec=er)
+            n2 = pb.buf(B, HW, Cout)
+            pb.groupnorm(hmid, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.beta"], n2, B, HW, Cout, eps=1e-5, silu=True)
+            if (p + ".skip_connection") in W:
+                skip = pb.buf(B, HW, Cout)
+                pb.igemm(x1, W[p + ".skip_connection"], skip, B, hh, ww, C1, Cout, a2=x2, C2=C2, bias=W[p + ".skip_connection.b"])
+            else:
+                assert x2 is None and C1 == Cout
+                skip = x1
+            out = pb.buf(B, HW, Cout)
+            pb.igemm(n2, W[p + ".out_layers.3"], out, B, hh, ww, Cout, Cout, KH=3, bias=W[p + ".out_layers.3.b"], residual=skip)
+            return out
+
+        def tblock(p, hcur, Cc, HW):
+            d = Cc // heads
+            ln = pb.buf(B, HW, Cc)
+            pb.layernorm(hcur, W[p + ".norm1.g"], W[p + ".norm1.beta"], ln, B * HW, Cc)
+            q = pb.buf(B, HW, Cc)
+            pb.igemm(ln, W[p + ".attn1.to_q"], q, B * HW, 1, 1, Cc, Cc)
+            if inject_idx is None:
+                Bk, Tk, ldt = B, HW, _cdiv(HW, 8) * 8     # V^T rows padded to 16 B (pad columns stay zero)
+                k = pb.buf(B, HW, Cc)
+                vt = pb.buf(B, Cc, ldt, zero=True)
+                pb.igemm(ln, W[p + ".attn1.to_k"], k, B * HW, 1, 1, Cc, Cc)
+                pb.igemm(ln, W[p + ".attn1.to_v"], vt, B, HW, 1, Cc, Cc, transpose_out=1, ldt=ldt)
+            else:
+                nr = len(inject_idx)
+                Bk, Tk, ldt = 1, nr * HW, _cdiv(nr * HW, 8) * 8
+                k = pb.buf(1, Tk, Cc)
+                vt = pb.buf(1, Cc, ldt, zero=True)
+                for j, bi in enumerate(inject_idx):   # K/V of the injected frame(s) only: B-fold fewer projection FLOPs
+                    src = ln[int(bi)]
+                    pb.igemm(src, W[p + ".attn1.to_k"], k[0, j * HW:(j + 1) * HW], HW, 1, 1, Cc, Cc)
+                    pb.igemm(src, W[p + ".attn1.to_v"], vt.view(-1)[j * HW:], 1, HW, 1, Cc, Cc, transpose_out=1, ldt=ldt)
+            a = pb.buf(B, HW, Cc)
+            pb.attention(q, k, vt, a, B, Bk, HW, Tk, heads, d, ldt)
+            h1 = pb.buf(B, HW, Cc)
+            pb.igemm(a, W[p + ".attn1.to_out.0"], h1, B * HW, 1, 1, Cc, Cc, bias=W[p + ".attn1.to_out.0.b"], residual=hcur)
+            # cross attention: K/V from the prompt, projected once in the prologue plan
+            ln2 = pb.buf(B, HW, Cc)
+            pb.layernorm(h1, W[p + ".norm2.g"], W[p + ".norm2.beta"], ln2, B * HW, Cc)
+            q2 = pb.buf(B, HW, Cc)
+            pb.igemm(ln2, W[p + ".attn2.to_q"], q2, B * HW, 1, 1, Cc, Cc)
+            k2 = pro.buf(B, n_ctx, Cc)
+            vt2 = pro.buf(B, Cc, ldt_ctx, zero=True)
+            cd = cfg["context_dim"]
+            pro.igemm(ctx, W[p + ".attn2.to_k"], k2, B * n_ctx, 1, 1, cd, Cc)
+            pro.igemm(ctx, W[p + ".attn2.to_v"], vt2, B, n_ctx, 1, cd, Cc, transpose_out=1, ldt=ldt_ctx)
+            a2 = pb.buf(B, HW, Cc)
+            pb.attention(q2, k2, vt2, a2, B, B, HW, n_ctx, heads, d, ldt_ctx)
+            h2 = pb.buf(B, HW, Cc)
+            pb.igemm(a2, W[p + ".attn2.to_out.0"], h2, B * HW, 1, 1, Cc, Cc, bias=W[p + ".attn2.to_out.0.b"], residual=h1)
+            ln3 = pb.buf(B, HW, Cc)
+            pb.layernorm(h2, W[p + ".norm3.g"], W[p + ".norm3.beta"], ln3, B * HW, Cc)
+            inner = self.shapes[p + ".ff.net.0.proj"][0] // 2
+            ff = pb.buf(B, HW, inner)
+            pb.igemm(ln3, W[p + ".ff.net.0.proj"], ff, B * HW, 1, 1, Cc, 2 * inner, bias=W[p + ".ff.net.0.proj.b"], act=2)
+            h3 = pb.buf(B, HW, Cc)
+            pb.igemm(ff, W[p + ".ff.net.2"], h3, B * HW, 1, 1, inner, Cc, bias=W[p + ".ff.net.2.b"], residual=h2)
+            return h3
+
+        def stransformer(p, x, Cc, HW, hh, ww, depth):
+            n = pb.buf(B, HW, Cc)
+            pb.groupnorm(x, W[p + ".norm.g"], W[p + ".norm.beta"], n, B, HW, Cc, eps=1e-6, silu=False)
+            hcur = pb.buf(B, HW, Cc)
+            pb.igemm(n, W[p + ".proj_in"], hcur, B, hh, ww, Cc, Cc, bias=W[p + ".proj_in.b"])
+            for i in range(depth):
+                hcur = tblock(f"{p}.transformer_blocks.{i}", hcur, Cc, HW)
+            out = pb.buf(B, HW, Cc)
+            pb.igemm(hcur, W[p + ".proj_out"], out, B, hh, ww, Cc, Cc, bias=W[p + ".proj_out.b"], residual=x)
+            return out
+
+        # ---- encoder ---------------------------------------------------------------------------------
+        cin_pad = _cdiv(cfg["in_channels"], self.ke) * self.ke
+        xh = pb.buf(B, h * w, cin_pad)
+        pb.nchw_to_nhwc(x_in, xh, B, cfg["in_channels"], h * w, cin_pad)
+        cur = pb.buf(B, h * w, mc)
+        pb.igemm(xh, W["input_blocks.0.0"], cur, B, h, w, cin_pad, mc, KH=3, bias=W["input_blocks.0.0.b"])
+        hs = [(cur, mc, h, w)]
+        ch, hh, ww = mc, h, w
+        td = list(cfg["transformer_depth"])
+        nlev = len(cfg["channel_mult"])
+        bi = 1
+        for lev in range(nlev):
+            cout = mc * cfg["channel_mult"][lev]
+            for _ in range(cfg["num_res_blocks"][lev]):
+                cur = resblock(f"input_blocks.{bi}.0", cur, ch, None, 0, cout, hh * ww, hh, ww)
+                ch = cout
+                depth = td.pop(0)
+                if depth > 0:
+                    cur = stransformer(f"input_blocks.{bi}.1", cur, ch, hh * ww, hh, ww, depth)
+                hs.append((cur, ch, hh, ww))
+                bi += 1
+            if lev != nlev - 1:
+                ho, wo = (hh + 1) // 2, (ww + 1) // 2
+                dn = pb.buf(B, ho * wo, ch)
+                pb.igemm(cur, W[f"input_blocks.{bi}.0.op"], dn, B, hh, ww, ch, ch, KH=3, stride=2, bias=W[f"input_blocks.{bi}.0.op.b"])
+                cur, hh, ww = dn, ho, wo
+                hs.append((cur, ch, hh, ww))
+                bi += 1
+        # ---- middle ----------------------------------------------------------------------------------
+        cur = resblock("middle_block.0", cur, ch, None, 0, ch, hh * ww, hh, ww)
+        cur = stransformer("middle_block.1", cur, ch, hh * ww, hh, ww, cfg["transformer_depth_middle"])
+        cur = resblock("middle_block.2", cur, ch, None, 0, ch, hh * ww, hh, ww)
+        # ---- decoder ---------------------------------------------------------------------------------
+        tdo = list(cfg["transformer_depth_output"])
+        bo = 0
+        for lev in reversed(range(nlev)):
+            cout = mc * cfg["channel_mult"][lev]
+            for i in range(cfg["num_res_blocks"][lev] + 1):
+                skip, cs, sh, sw = hs.pop()
+                assert (sh, sw) == (hh, ww)
+                cur = resblock(f"output_blocks.{bo}.0", cur, ch, skip, cs, cout, hh * ww, hh, ww)
+                ch = cout
+                depth = tdo.pop()                      # the reference pops from the END (openaimodel.py:737)
+                j = 1
+                if depth > 0:
+                    cur = stransformer(f"output_blocks.{bo}.1", cur, ch, hh * ww, hh, ww, depth)
+                    j = 2
+                if lev > 0 and i == cfg["num_res_blocks"][lev]:
+                    up = pb.buf(B, 4 * hh * ww, ch)
+                    pb.igemm(cur, W[f"output_blocks.{bo}.{j}.conv"], up, B, hh, ww, ch, ch, KH=3, upsample=1,
+                             bias=W[f"output_blocks.{bo}.{j}.conv.b"])
+                    cur, hh, ww = up, 2 * hh, 2 * ww
+                bo += 1
+        # ---- out -------------------------------------------------------------------------------------
+        n = pb.buf(B, hh * ww, ch)
+        pb.groupnorm(cur, W["out.0.g"], W["out.0.beta"], n, B, hh * ww, ch, eps=1e-5, silu=True)
+        oc = cfg["out_channels"]
+        o_nhwc = pb.buf(B, hh * ww, oc, dtype=torch.float32)
+        pb.igemm(n, W["out.2"], o_nhwc, B, hh, ww, ch, oc, KH=3, bias=W["out.2.b"], out_f32=1)
+        out = pb.buf(B, oc, hh, ww, dtype=torch.float32)
+        pb.nhwc_to_nchw(o_nhwc, out, B, oc, hh * ww, oc)
+        flops = pb.flops
+        return dict(prologue=pro.take(), step=pb.take(), x=x_in, t=t_in, ctx=ctx, out=out, flops=flops)

@@ -1,0 +1,93 @@
+"""GPU parity of the lowered UNet / VAE decoder against the golden vectors produced by the reference modules
+(tests/golden/unet_*.npz, vae_dec.npz).  fp32 path: exact-fp32 MFMA, tolerance 2e-3 abs on O(1) outputs (the
+accumulation order differs from the CPU conv kernels); fp16 path: the reference-on-ROCm precision, tolerance 6e-2."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _sd(name, seed):
+    from stable_renderer_amd import synth
+    with open(os.path.join(GOLD, name)) as f:
+        k = json.load(f)
+    return synth.synth_state_dict([(n, tuple(s)) for n, s in k["names_shapes"]], seed=seed, norm_names=k["norm_names"])
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def run_unet(sd, cfg, dtype, x, t, ctx, inject=None):
+    from stable_renderer_amd.unet import UNet
+    net = UNet(sd, cfg, dtype=dtype)
+    B = x.shape[0]
+    p = net.build(B, x.shape[2], x.shape[3], inject_idx=inject, n_ctx=ctx.shape[1])
+    p["x"].copy_(x)
+    p["t"].copy_(t)
+    p["ctx"].copy_(ctx.to(dtype))
+    p["prologue"].run()
+    p["step"].run()
+    torch.cuda.synchronize()
+    return p["out"].cpu(), p
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
+def test_unet_tiny(dtype, atol):
+    from stable_renderer_amd.unet import SD15_CFG
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    d = np.load(os.path.join(GOLD, "unet_tiny.npz"))
+    sd = _sd("unet_tiny_keys.json", 1)
+    y, _ = run_unet(sd, cfg, dtype, T(d["x"]), T(d["t"]), T(d["ctx"]))
+    ref = T(d["y"])
+    assert (y - ref).abs().max().item() < atol * max(1.0, ref.abs().max().item()), (y - ref).abs().max()
+    yi, _ = run_unet(sd, cfg, dtype, T(d["x"]), T(d["t"]), T(d["ctx"]), inject=d["inj_idx"].tolist())
+    refi = T(d["y_inj"])
+    assert (yi - refi).abs().max().item() < atol * max(1.0, refi.abs().max().item()), (yi - refi).abs().max()
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
+def test_unet_sd15_shapes(dtype, atol):
+    from stable_renderer_amd.unet import SD15_CFG
+    d = np.load(os.path.join(GOLD, "unet_sd15_16.npz"))
+    sd = _sd("unet_sd15_keys.json", 0)
+    y, p = run_unet(sd, SD15_CFG, dtype, T(d["x"]), T(d["t"]), T(d["ctx"]))
+    ref = T(d["y"])
+    err = (y - ref).abs().max().item()
+    assert err < atol * max(1.0, ref.abs().max().item()), err
+    # graph replay gives the same bits as the eager plan
+    s = torch.cuda.Stream()
+    p["step"].capture(s)
+    with torch.cuda.stream(s):
+        p["step"].launch()
+    s.synchronize()
+    assert torch.equal(p["out"].cpu(), y)
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
+def test_vae_decoder(dtype, atol):
+    from stable_renderer_amd.vae import VAEDecoder
+    d = np.load(os.path.join(GOLD, "vae_dec.npz"))
+    sd = _sd("vae_dec_keys.json", 2)
+    dec = VAEDecoder(sd, dtype=dtype)
+    z = T(d["z"])
+    p = dec.build(z.shape[0], z.shape[2], z.shape[3], clamp=False)
+    p["z"].copy_(z)
+    p["plan"].run()
+    torch.cuda.synchronize()
+    raw = p["img"].cpu().permute(0, 3, 1, 2)
+    ref = T(d["y"])
+    err = (raw - ref).abs().max().item()
+    assert err < atol * max(1.0, ref.abs().max().item()), err
+    p2 = dec.build(z.shape[0], z.shape[2], z.shape[3], clamp=True)
+    p2["z"].copy_(z)
+    p2["plan"].run()
+    torch.cuda.synchronize()
+    img = p2["img"].cpu()
+    assert (img - T(d["img"])).abs().max().item() < atol
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
