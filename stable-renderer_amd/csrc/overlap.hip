@@ -180,11 +180,13 @@ __global__ void corrmap_pass1(const int4* __restrict__ ids, const float* __restr
   atomicMax(&winner[cell], i);
 }
 __global__ void corrmap_pass2(const float* __restrict__ frame, int Cf, const int4* __restrict__ ids, const int* __restrict__ src_index, int n,
-                              int V, const int* __restrict__ winner, _Float16* __restrict__ values, uint8_t* __restrict__ writtens) {
+                              int V, int kk, const int* __restrict__ winner, const int* __restrict__ err,
+                              _Float16* __restrict__ values, uint8_t* __restrict__ writtens) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (*err) return;                                        // the reference raises before writing anything of this frame
   const int4 v = ids[i];
-  if (v.z < 0 || v.w < 0 || v.w >= V) return;
+  if (v.z < 0 || v.z >= kk || v.w < 0 || v.w >= V) return;
   const int cell = v.z * V + v.w;
   if (winner[cell] != i) return;                           // (cells of filtered rows keep winner == -1 / other)
   const int64_t src = src_index ? src_index[i] : i;
@@ -276,7 +278,7 @@ extern "C" int sr_corrmap_update(const float* frame, int32_t Cf, const int32_t* 
   if (hipMemsetAsync(winner, 0xFF, (size_t)kk * V * 4, st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "memset");
   hipLaunchKernelGGL(corrmap_pass1, g1(n), dim3(256), 0, st, (const int4*)ids, mask, n, sprite, material, chk_s, chk_m, mode_first, writtens, kk, V,
                      winner, err);
-  hipLaunchKernelGGL(corrmap_pass2, g1(n), dim3(256), 0, st, frame, Cf, (const int4*)ids, src_index, n, V, winner, (_Float16*)values, writtens);
+  hipLaunchKernelGGL(corrmap_pass2, g1(n), dim3(256), 0, st, frame, Cf, (const int4*)ids, src_index, n, V, kk, winner, err, (_Float16*)values, writtens);
   SR_CHECK_LAUNCH("sr_corrmap_update");
   return SR_OK;
 }

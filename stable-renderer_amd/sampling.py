@@ -1,0 +1,217 @@
+"""Host side of the sampling stack (schedules + the per-step driver).  Mirrors, with the same names and argument
+meaning: ``ModelSamplingDiscrete`` (comfyUI/comfy/model_sampling.py:75-150), ``calculate_sigmas_scheduler`` /
+``KSampler`` (comfy/samplers.py:415-451, 937-1078), ``calc_cond_uncond_batch`` + ``sampling_function`` (batch =
+[uncond | cond], CFG; samplers.py:176-358), ``BaseModel.apply_model`` with EPS scaling (comfy/model_base.py:93-127),
+the k-diffusion loops ``sample_euler`` / ``sample_ddpm`` / ``sample_lcm`` (comfy/k_diffusion/sampling.py:129-149,
+749-793) and ``custom_ksampler`` (comfyUI/nodes.py:1438-1495).  The sigma schedule is a few hundred scalars computed
+once on the host; everything per step (UNet plan, CFG, sampler update, latent overlap) runs as HIP kernels.
+"""
+import math
+
+import torch
+
+from . import ops as O
+
+LATENT_SCALE = 0.18215            # comfy/latent_formats.py SD15.scale_factor
+SCHEDULER_NAMES = ["normal", "karras", "exponential", "sgm_uniform", "simple", "ddim_uniform"]
+SAMPLER_NAMES = ["euler", "ddim", "ddpm", "lcm"]
+
+
+class ModelSamplingDiscrete:
+    def __init__(self, linear_start=0.00085, linear_end=0.012, timesteps=1000):
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2
+        ac = torch.cumprod(1.0 - betas, dim=0)
+        self.sigmas = (((1 - ac) / ac) ** 0.5).float()
+        self.log_sigmas = self.sigmas.log()
+
+    @property
+    def sigma_min(self):
+        return self.sigmas[0]
+
+    @property
+    def sigma_max(self):
+        return self.sigmas[-1]
+
+    def timestep(self, sigma):
+        sigma = torch.as_tensor(sigma, dtype=torch.float32)
+        d = sigma.log().reshape(1, -1) - self.log_sigmas[:, None]
+        return d.abs().argmin(dim=0).view(sigma.shape)
+
+    def sigma(self, timestep):
+        t = torch.clamp(torch.as_tensor(timestep).float(), min=0, max=len(self.sigmas) - 1)
+        lo, hi, w = t.floor().long(), t.ceil().long(), t.frac()
+        return ((1 - w) * self.log_sigmas[lo] + w * self.log_sigmas[hi]).exp()
+
+
+def calculate_sigmas_scheduler(ms, scheduler_name, steps):
+    if scheduler_name in ("normal", "sgm_uniform"):
+        start, end = ms.timestep(ms.sigma_max), ms.timestep(ms.sigma_min)
+        ts = torch.linspace(start, end, steps + 1)[:-1] if scheduler_name == "sgm_uniform" else torch.linspace(start, end, steps)
+        return torch.FloatTensor([float(ms.sigma(t)) for t in ts] + [0.0])
+    if scheduler_name == "simple":
+        ss = len(ms.sigmas) / steps
+        return torch.FloatTensor([float(ms.sigmas[-(1 + int(i * ss))]) for i in range(steps)] + [0.0])
+    if scheduler_name == "ddim_uniform":
+        ss = max(len(ms.sigmas) // steps, 1)
+        sig, i = [], 1
+        while i < len(ms.sigmas):
+            sig.append(float(ms.sigmas[i]))
+            i += ss
+        return torch.FloatTensor(sig[::-1] + [0.0])
+    if scheduler_name == "karras":
+        rho = 7.0
+        ramp = torch.linspace(0, 1, steps)
+        a, b = float(ms.sigma_min) ** (1 / rho), float(ms.sigma_max) ** (1 / rho)
+        s = (b + ramp * (a - b)) ** rho
+        return torch.cat([s, s.new_zeros([1])])
+    if scheduler_name == "exponential":
+        s = torch.linspace(math.log(float(ms.sigma_max)), math.log(float(ms.sigma_min)), steps).exp()
+        return torch.cat([s, s.new_zeros([1])])
+    raise ValueError("error invalid scheduler " + str(scheduler_name))
+
+
+class SamplingCallbackContext:
+    """comfyUI/types/runtime.py:543-593 (fields a corresponder reads)."""
+
+    def __init__(self, noise, step_index, denoised, total_steps, timesteps, sigmas):
+        self.noise, self.step_index, self.denoised = noise, step_index, denoised
+        self.total_steps, self.timesteps, self.sigmas = total_steps, timesteps, sigmas
+
+    @property
+    def timestep(self):
+        return self.timesteps[self.step_index]
+
+    @property
+    def sigma(self):
+        return self.sigmas[self.step_index]
+
+
+class KSampler:
+    """Schedule holder (comfy/samplers.py:954-1003).  ``timesteps`` is NOT re-sliced when denoise < 1, exactly as in
+    the reference (samplers.py:1000-1003 vs types/runtime.py:585-588)."""
+
+    def __init__(self, steps, sampler="euler", scheduler="normal", denoise=None, model_sampling=None):
+        self.ms = model_sampling or ModelSamplingDiscrete()
+        self.sampler_name = sampler if sampler in SAMPLER_NAMES else SAMPLER_NAMES[0]
+        self.scheduler = scheduler if scheduler in SCHEDULER_NAMES else SCHEDULER_NAMES[0]
+        self.steps = steps
+        if denoise is None or denoise > 0.9999:
+            self.sigmas = calculate_sigmas_scheduler(self.ms, self.scheduler, steps)
+            self.timesteps = [int(self.ms.timestep(s)) for s in self.sigmas]
+        else:
+            new_steps = int(steps / denoise)
+            sig = calculate_sigmas_scheduler(self.ms, self.scheduler, new_steps)
+            self.timesteps = [int(self.ms.timestep(s)) for s in sig]
+            self.sigmas = sig[-(steps + 1):]
+
+
+class DiffusionRunner:
+    """One UNet (HIP plan) + sampler state for a fixed batch of N frames at latent size (h, w).
+
+    ``sample()`` is the body of custom_ksampler -> comfy.sample.sample -> KSampler.sample -> sampler loop with the
+    model call replaced by the native plan; the latent stays resident in HBM for the whole run."""
+
+    def __init__(self, unet, N, h, w, cfg_scale, n_ctx=77, use_graph=True):
+        self.unet, self.N, self.h, self.w = unet, N, h, w
+        self.cfg_scale = float(cfg_scale)
+        self.copies = 1 if math.isclose(self.cfg_scale, 1.0) else 2     # samplers.py:335 (skip uncond at cfg 1)
+        self.n_ctx = n_ctx
+        self.use_graph = use_graph
+        self.ms = ModelSamplingDiscrete()
+        self._plan = None
+        self._inject = "unset"
+        dev = unet.device
+        self.x = torch.zeros(N, 4, h, w, dtype=torch.float32, device=dev)
+        self.den = torch.empty_like(self.x)
+        self.d = torch.empty_like(self.x)
+        self._stream = torch.cuda.Stream(device=dev) if use_graph else None
+
+    def _ensure_plan(self, inject_idx):
+        key = None if inject_idx is None else tuple(int(i) for i in inject_idx)
+        if self._plan is None or self._inject != key:
+            self._plan = self.unet.build(self.N * self.copies, self.h, self.w, inject_idx=key, n_ctx=self.n_ctx)
+            self._inject = key
+            self._captured = False
+        return self._plan
+
+    def set_conditioning(self, positive, negative):
+        """positive / negative: (1 | N, n_ctx, ctx_dim) text embeddings (CONDRegular.process_cond repeats a single
+        embedding to the batch, comfy/conds.py:23-26).  Batch order = [uncond frames..., cond frames...]."""
+        self._pos, self._neg = positive, negative
+
+    def _load_ctx(self, p):
+        N = self.N
+        dt = p["ctx"].dtype
+        pos = self._pos.to(p["ctx"].device).to(dt).expand(N, -1, -1)
+        if self.copies == 2:
+            neg = self._neg.to(p["ctx"].device).to(dt).expand(N, -1, -1)
+            p["ctx"][:N].copy_(neg)
+            p["ctx"][N:].copy_(pos)
+        else:
+            p["ctx"].copy_(pos)
+        p["prologue"].run()
+
+    def model_eps(self, p, sigma, timestep_index):
+        """calc_cond_uncond_batch + apply_model: xin = x/sqrt(sigma^2+1) for both chunks, t = argmin|log sigma|"""
+        n = self.x.numel()
+        O.eps_scale_input(self.x, p["x"], self.copies, sigma)
+        p["t"].fill_(float(timestep_index))
+        if self.use_graph:
+            if not self._captured:
+                torch.cuda.current_stream().synchronize()
+                p["step"].capture(self._stream)
+                self._captured = True
+                self._stream.synchronize()
+            p["step"].launch()
+        else:
+            p["step"].run()
+        return p["out"]
+
+    def sample(self, noise, steps, sampler_name, scheduler, denoise=1.0, latent_image=None, seed=None,
+               inject_n_rand=None, step_callback=None, noise_fn=None):
+        """-> samples (N,4,h,w) fp32 on device (already divided by the latent scale, samplers.py:933).
+
+        RNG draw order on the *global CPU generator* replicates the reference: custom_ksampler's seed draw
+        (nodes.py:1455), SAMPLER_METHOD's reseed+draw for "ddim" (samplers.py:766-768), pre_atten_inject's randint
+        on the first attention block (corresponder.py:204-205), then the sampler's per-step randn_like."""
+        ks = KSampler(steps, sampler_name, scheduler, denoise, self.ms)
+        sig = ks.sigmas
+        sampler = ks.sampler_name
+        dev = self.x.device
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 32, (1,)).item())
+        latent = torch.zeros_like(noise) if latent_image is None else latent_image * LATENT_SCALE
+        if sampler == "ddim":
+            g = torch.manual_seed(seed + 1)
+            torch.randn(tuple(noise.shape), generator=g, device="cpu")
+        max_denoise = math.isclose(float(self.ms.sigma_max), float(sig[0]), rel_tol=1e-05) or float(sig[0]) > float(self.ms.sigma_max)
+        s0 = float(torch.sqrt(1.0 + sig[0] ** 2.0)) if max_denoise else float(sig[0])
+        self.x.copy_(noise.to(dev, torch.float32))
+        O.axpby(self.x, latent.to(dev, torch.float32).contiguous(), 1.0, s0)        # x = noise*s0 + latent
+        inject = None
+        if inject_n_rand is not None and inject_n_rand >= 0:
+            B = self.N * self.copies
+            inject = torch.randint(1, B, (inject_n_rand,)).tolist()       # global RNG; B counts cond + uncond entries
+        p = self._ensure_plan(inject)
+        self._load_ctx(p)
+        if noise_fn is None:
+            def noise_fn():
+                return torch.randn(tuple(self.x.shape), dtype=torch.float32).to(dev)    # default_noise_sampler (CPU x)
+        for i in range(len(sig) - 1):
+            s, sn = float(sig[i]), float(sig[i + 1])
+            eps = self.model_eps(p, s, int(self.ms.timestep(sig[i])))
+            O.cfg_denoise(self.x, eps, self.den, self.d if sampler in ("euler", "ddim") else None, self.copies, s, self.cfg_scale)
+            if step_callback is not None:
+                step_callback(SamplingCallbackContext(self.x, i, self.den, len(sig) - 1, ks.timesteps, sig.tolist()))
+            if sampler in ("euler", "ddim"):
+                O.euler_step(self.x, self.d, sn - s)
+            elif sampler == "ddpm":
+                O.ddpm_step(self.x, self.den, noise_fn() if sn > 0 else None, s, sn)
+            elif sampler == "lcm":
+                O.lcm_step(self.x, self.den, noise_fn() if sn > 0 else None, sn)
+            else:
+                raise ValueError(sampler)
+        out = torch.empty_like(self.x)
+        out.zero_()
+        O.axpby(out, self.x, 1.0 / LATENT_SCALE, 0.0)
+        return out, inject
