@@ -9,7 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libsr_hip.so")
 SOURCES = ["errors.cpp", "igemm.hip", "norm.hip", "attention.hip", "eltwise.hip", "overlap.hip", "plan.hip", "raster.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# the rasterizer's fp32 evaluation order is its specification (bit parity with oracle/raster_ref.c): no FMA contraction
+EXTRA = {"raster.hip": ["-ffp-contract=off"]}
 HEADERS = ["sr_common.h", os.path.join("..", "..", "include", "sr_hip.h")]
 
 
@@ -36,7 +38,7 @@ def build(force=False, verbose=False):
     for s in srcs:
         obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
         if force or _needs(s, obj):
-            cmd = [cc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(HERE, s), "-o", obj]
+            cmd = [cc] + FLAGS + EXTRA.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(HERE, s), "-o", obj]
             jobs.append((s, cmd))
 
     def run(job):

@@ -1,0 +1,293 @@
+"""Headless scene description + G-buffer rasterisation front-end.
+
+Host-side mirror of the pieces of the reference engine that feed the G-buffer pass: ``Mesh.Sphere / Mesh.Plane /
+Mesh.Load`` (engine/static/mesh/mesh.py:321-569), ``Camera`` matrices (engine/runtime/components/camera/camera.py:
+94-120: glm.lookAt / glm.perspective, RH, -1..1 depth), ``Transform`` TRS (engine/runtime/components/transform.py:
+339-352), the MV / MV_IT uniforms (engine/managers/runtimeManager.py:165-181), ``MeshRenderer`` / ``CorrMapRenderer``
+draw parameters (runtime/components/renderer/mesh_renderer.py:76-123, corrmap_renderer.py:122-149) and the task order
++ depth-test rule of ``RenderManager`` (engine/managers/renderManager.py:499-522).  Matrices are a few dozen scalars
+computed on the host in fp32 with GLM's formulas (PyGLM itself is absent: parity unpinned); all per-vertex
+and per-pixel work is in ``sr_raster_draw``.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops as O
+
+F = np.float32
+
+
+# ---- GLM restatement (column-major 4x4, numpy float32; M[col][row] like glm) --------------------------------------
+def perspective(fovy_rad, aspect, near, far):
+    t = F(math.tan(fovy_rad / 2.0))
+    m = np.zeros((4, 4), F)
+    m[0][0] = F(1.0) / (F(aspect) * t)
+    m[1][1] = F(1.0) / t
+    m[2][2] = -F(far + near) / F(far - near)
+    m[2][3] = -F(1.0)
+    m[3][2] = -(F(2.0) * F(far) * F(near)) / F(far - near)
+    return m
+
+
+def _norm(v):
+    v = np.asarray(v, F)
+    return v / F(np.sqrt(np.dot(v, v)))
+
+
+def look_at(eye, center, up):
+    eye, center, up = np.asarray(eye, F), np.asarray(center, F), np.asarray(up, F)
+    f = _norm(center - eye)
+    s = _norm(np.cross(f, up))
+    u = np.cross(s, f)
+    m = np.eye(4, dtype=F)
+    m[0][0], m[1][0], m[2][0] = s
+    m[0][1], m[1][1], m[2][1] = u
+    m[0][2], m[1][2], m[2][2] = -f
+    m[3][0], m[3][1], m[3][2] = -np.dot(s, eye), -np.dot(u, eye), np.dot(f, eye)
+    return m
+
+
+def translate(v):
+    m = np.eye(4, dtype=F)
+    m[3][:3] = np.asarray(v, F)
+    return m
+
+
+def scale(v):
+    m = np.eye(4, dtype=F)
+    v = np.asarray(v, F) * np.ones(3, F)
+    m[0][0], m[1][1], m[2][2] = v
+    return m
+
+
+def rotate_y(deg):
+    a = math.radians(deg)
+    c, s = F(math.cos(a)), F(math.sin(a))
+    m = np.eye(4, dtype=F)
+    m[0][0], m[0][2], m[2][0], m[2][2] = c, -s, s, c
+    return m
+
+
+def matmul(a, b):
+    """glm a*b for [col][row] storage"""
+    return (b.astype(F) @ a.astype(F)).astype(F)
+
+
+def inverse_transpose(m):
+    mm = m.astype(np.float64).T                      # to row-major math matrix
+    it = np.linalg.inv(mm).T
+    return it.T.astype(F)                            # back to [col][row]
+
+
+# ---- meshes ------------------------------------------------------------------------------------------------------
+def strip_to_triangles(idx):
+    """GL_TRIANGLE_STRIP -> triangle list keeping orientation; provoking (flat) vertex stays the last one."""
+    tris = []
+    for k in range(len(idx) - 2):
+        a, b, c = idx[k], idx[k + 1], idx[k + 2]
+        tris.append((a, b, c) if k % 2 == 0 else (b, a, c))
+    return np.asarray(tris, np.int32)
+
+
+class Mesh:
+    def __init__(self, positions, normals, uvs, tris, colors=None, vertex_ids=None, cullback=True, name=None):
+        self.positions = np.ascontiguousarray(positions, F)
+        self.normals = np.ascontiguousarray(normals, F)
+        self.uvs = np.ascontiguousarray(uvs, F)
+        self.tris = np.ascontiguousarray(tris, np.int32)
+        self.colors = None if colors is None else np.ascontiguousarray(colors, F)
+        self.vertex_ids = None if vertex_ids is None else np.ascontiguousarray(vertex_ids, np.int32)
+        self.cullback = cullback
+        self.name = name
+        self._dev = None
+
+    def device(self, dev):
+        if self._dev is None:
+            t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+            self._dev = dict(pos=t(self.positions), normal=t(self.normals), uv=t(self.uvs), tris=t(self.tris),
+                             color=t(self.colors), vid=t(self.vertex_ids))
+        return self._dev
+
+    @staticmethod
+    def Sphere(segment=32):
+        """mesh.py:518-569: one indexed TRIANGLE_STRIP; the seam column j == segment is not referenced and the id VBO
+        is filled from the index buffer (mesh.py:279-281)."""
+        pos, nrm, uv = [], [], []
+        for i in range(segment + 1):
+            for j in range(segment + 1):
+                xs, ys = j / segment, i / segment
+                x = math.cos(xs * 2 * math.pi) * math.sin(ys * math.pi)
+                y = math.cos(ys * math.pi)
+                z = math.sin(xs * 2 * math.pi) * math.sin(ys * math.pi)
+                pos.append((x, y, z)); nrm.append((x, y, z)); uv.append((xs, ys))
+        idx = []
+        for i in range(segment):
+            for j in range(segment):
+                idx.append((i + 1) * (segment + 1) + j)
+                idx.append(i * (segment + 1) + j)
+        return Mesh(pos, nrm, uv, strip_to_triangles(idx), name="sphere")
+
+    @staticmethod
+    def Plane(edge=1):
+        """mesh.py:472-515"""
+        xs = np.linspace(-0.5, 0.5, edge + 1)
+        pos, nrm, uv = [], [], []
+        for z in xs:
+            for x in xs:
+                pos.append((x, 0, z)); nrm.append((0, 1, 0)); uv.append((x + 0.5, z + 0.5))
+        tris = []
+        for i in range(edge):
+            for j in range(edge):
+                a, b, c, d = i * (edge + 1) + j, (i + 1) * (edge + 1) + j, (i + 1) * (edge + 1) + j + 1, i * (edge + 1) + j + 1
+                tris += [(a, b, c), (a, c, d)]
+        return Mesh(pos, nrm, uv, tris, name="plane")
+
+    @staticmethod
+    def Load(path):
+        """Wavefront OBJ (positions / uvs / normals, polygons fan-triangulated).  The reference loads through assimp
+        (Triangulate | CalcTangentSpace | JoinIdenticalVertices, mesh.py:337-338), whose vertex order is not
+        reproducible without assimp: vertices here are unique (v, vt, vn) triples in first-use order."""
+        vs, vts, vns, verts, index, tris = [], [], [], [], {}, []
+        with open(path) as f:
+            for line in f:
+                p = line.split()
+                if not p:
+                    continue
+                if p[0] == "v":
+                    vs.append(tuple(map(float, p[1:4])))
+                elif p[0] == "vt":
+                    vts.append((float(p[1]), float(p[2])))
+                elif p[0] == "vn":
+                    vns.append(tuple(map(float, p[1:4])))
+                elif p[0] == "f":
+                    ids = []
+                    for tok in p[1:]:
+                        q = (tok.split("/") + ["", ""])[:3]
+                        key = (int(q[0]), int(q[1]) if q[1] else 0, int(q[2]) if q[2] else 0)
+                        if key not in index:
+                            index[key] = len(verts)
+                            verts.append(key)
+                        ids.append(index[key])
+                    for k in range(1, len(ids) - 1):
+                        tris.append((ids[0], ids[k], ids[k + 1]))
+        fix = lambda i, n: i - 1 if i > 0 else n + i
+        pos = [vs[fix(a, len(vs))] for a, _, _ in verts]
+        uv = [vts[fix(b, len(vts))] if b else (0.0, 0.0) for _, b, _ in verts]
+        if all(c for _, _, c in verts):
+            nrm = [vns[fix(c, len(vns))] for _, _, c in verts]
+        else:
+            nrm = np.zeros((len(pos), 3), F)
+            P = np.asarray(pos, F)
+            for a, b, c in tris:
+                n = np.cross(P[b] - P[a], P[c] - P[a])
+                nrm[a] += n; nrm[b] += n; nrm[c] += n
+            nrm = nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+        return Mesh(pos, nrm, uv, tris, name=path)
+
+
+class Camera:
+    def __init__(self, position, target, up=(0, 1, 0), fov=45.0, near=0.1, far=100.0):
+        self.position, self.target, self.up = position, target, up
+        self.fov, self.near, self.far = fov, near, far
+
+    def view(self):
+        return look_at(self.position, self.target, self.up)
+
+    def projection(self, aspect):
+        return perspective(math.radians(self.fov), aspect, self.near, self.far)
+
+
+class RenderOrder:
+    OPAQUE, TRANSPARENT, OVERLAY = 1000, 2000, 3000
+
+
+class DrawTask:
+    """One (mesh x material) G-buffer task.  render_mode: 0 NORMAL, 1 BAKED, 2 BAKING (engine/static/enums.py:174-238)."""
+
+    def __init__(self, mesh, model, sprite_id=1, material_id=1, render_mode=0, corrmap_k=3, use_texcoord_id=False,
+                 id_size=(512, 512), noise_tex=None, diffuse_tex=None, corrmap=None, order=RenderOrder.OPAQUE,
+                 has_vertex_color=False):
+        self.mesh, self.model = mesh, np.asarray(model, F)
+        self.sprite_id, self.material_id, self.render_mode, self.corrmap_k = sprite_id, material_id, render_mode, corrmap_k
+        self.use_texcoord_id, self.id_size = use_texcoord_id, id_size
+        self.noise_tex, self.diffuse_tex, self.corrmap = noise_tex, diffuse_tex, corrmap
+        self.order, self.has_vertex_color = order, has_vertex_color
+
+
+def draw_params(task, view, proj):
+    """-> dict of the uniforms of one task (shared by the HIP path and the oracle harness)"""
+    MV = matmul(view, task.model)
+    return dict(MV=MV.reshape(-1), MV_IT=inverse_transpose(MV).reshape(-1), P=np.asarray(proj, F).reshape(-1),
+                depth_test=0 if RenderOrder.TRANSPARENT <= task.order < RenderOrder.OVERLAY else 1)
+
+
+class GBuffer:
+    """The six MRT planes + depth as HBM tensors (formats of renderManager.py:206-391)."""
+
+    def __init__(self, W, H, device="cuda"):
+        self.W, self.H = W, H
+        dev = torch.device(device)
+        self.color = torch.zeros(H, W, 4, dtype=torch.float16, device=dev)
+        self.id = torch.zeros(H, W, 4, dtype=torch.int32, device=dev)
+        self.pos = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
+        self.normal_depth = torch.zeros(H, W, 4, dtype=torch.float16, device=dev)
+        self.noise = torch.zeros(H, W, 4, dtype=torch.float16, device=dev)
+        self.canny = torch.zeros(H, W, 3, dtype=torch.float32, device=dev)
+        self.zbuf = torch.ones(H, W, dtype=torch.float32, device=dev)
+        g = L.GBuffer()
+        g.color, g.id, g.pos, g.normal_depth = O._p(self.color), O._p(self.id), O._p(self.pos), O._p(self.normal_depth)
+        g.noise, g.canny, g.zbuf, g.W, g.H = O._p(self.noise), O._p(self.canny), O._p(self.zbuf), W, H
+        self.c = g
+        self._scratch = None
+
+    def clear(self):
+        L.check(L.lib().sr_gbuffer_clear(C.byref(self.c), O.stream_ptr()))
+
+    def draw(self, task, view, proj):
+        dev = self.color.device
+        md = task.mesh.device(dev)
+        up = draw_params(task, view, proj)
+        d = L.Draw()
+        d.pos, d.normal, d.uv, d.color, d.vertex_id, d.tris = (O._p(md["pos"]), O._p(md["normal"]), O._p(md["uv"]),
+                                                               O._p(md["color"]), O._p(md["vid"]), O._p(md["tris"]))
+        d.nv, d.nt = task.mesh.positions.shape[0], task.mesh.tris.shape[0]
+        d.MV[:] = up["MV"].tolist(); d.MV_IT[:] = up["MV_IT"].tolist(); d.P[:] = up["P"].tolist()
+        d.sprite_id, d.material_id, d.corrmap_k = task.sprite_id, task.material_id, task.corrmap_k
+        d.use_texcoord_id, d.render_mode = int(task.use_texcoord_id), task.render_mode
+        d.has_vertex_color, d.depth_test, d.cull_back = int(task.has_vertex_color), up["depth_test"], int(task.mesh.cullback)
+        d.id_w, d.id_h = task.id_size
+        def dev_tex(name, dtype):
+            t = getattr(task, name)
+            if t is None:
+                return None
+            if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):      # textures must be HBM resident
+                cache = task.__dict__.setdefault("_dev_tex", {})
+                if name not in cache or cache[name][0] is not t:
+                    cache[name] = (t, t.to(dev, dtype).contiguous())
+                t = cache[name][1]
+            if t.dim() != 3 or t.shape[-1] != 4:
+                raise ValueError(f"{name} must be (H, W, 4)")
+            return t
+        ntex, dtex = dev_tex("noise_tex", torch.float16), dev_tex("diffuse_tex", torch.float32)
+        if ntex is not None:
+            d.noise_tex, d.noise_h, d.noise_w = O._p(ntex), ntex.shape[0], ntex.shape[1]
+        if dtex is not None:
+            d.diffuse_tex, d.diffuse_h, d.diffuse_w = O._p(dtex), dtex.shape[0], dtex.shape[1]
+        if task.corrmap is not None:
+            d.corrmap_tex, d.corr_h, d.corr_w = O._p(task.corrmap._values), task.corrmap.height, task.corrmap.width
+        need = L.lib().sr_raster_scratch_bytes(d.nt, self.W, self.H)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        L.check(L.lib().sr_raster_draw(C.byref(d), C.byref(self.c), O._p(self._scratch), self._scratch.numel(), O.stream_ptr()))
+
+    def render(self, tasks, camera):
+        """RenderManager.on_frame_run's G-buffer part: clear, tasks sorted by order (stable), depth test off for the
+        TRANSPARENT queue (renderManager.py:508-513)."""
+        view, proj = camera.view(), camera.projection(self.W / self.H)
+        self.clear()
+        for t in sorted(tasks, key=lambda t: t.order):
+            self.draw(t, view, proj)
