@@ -93,7 +93,8 @@ class OverlapCorresponder:
         idx = engine_data.id_maps.overlap_index(x.shape[2], x.shape[3])
         idx.step(x, self.step_finished_inject_ratio)
 
-    finished = _update_corrmaps
+    # NB the reference's OverlapCorresponder defines no ``finished`` (corresponder.py:157-376), so its node returns a
+    # do-nothing VAE callback (_nodes/samplers.py:113-125): corr-maps are only baked by DefaultCorresponder.finished.
 
 
 __all__ = ['Corresponder', 'DefaultCorresponder', 'OverlapCorresponder']

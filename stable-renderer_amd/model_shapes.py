@@ -1,0 +1,117 @@
+"""(name, shape) lists of the reference checkpoints' parameter tensors, in the reference modules' ``state_dict()``
+order (UNetModel.__init__, openaimodel.py:452-839; Decoder.__init__, model.py:541-615).  Used to create seeded
+synthetic weights of the real architecture when no checkpoint is available (there is no network)."""
+
+
+def _res(p, cin, cout, emb, out):
+    out += [(f"{p}.in_layers.0.weight", (cin,)), (f"{p}.in_layers.0.bias", (cin,)),
+            (f"{p}.in_layers.2.weight", (cout, cin, 3, 3)), (f"{p}.in_layers.2.bias", (cout,)),
+            (f"{p}.emb_layers.1.weight", (cout, emb)), (f"{p}.emb_layers.1.bias", (cout,)),
+            (f"{p}.out_layers.0.weight", (cout,)), (f"{p}.out_layers.0.bias", (cout,)),
+            (f"{p}.out_layers.3.weight", (cout, cout, 3, 3)), (f"{p}.out_layers.3.bias", (cout,))]
+    if cin != cout:
+        out += [(f"{p}.skip_connection.weight", (cout, cin, 1, 1)), (f"{p}.skip_connection.bias", (cout,))]
+    return [f"{p}.in_layers.0.weight", f"{p}.out_layers.0.weight"]
+
+
+def _st(p, c, ctx, depth, out):
+    norms = [f"{p}.norm.weight"]
+    out += [(f"{p}.norm.weight", (c,)), (f"{p}.norm.bias", (c,)), (f"{p}.proj_in.weight", (c, c, 1, 1)), (f"{p}.proj_in.bias", (c,))]
+    for i in range(depth):
+        b = f"{p}.transformer_blocks.{i}"
+        out += [(f"{b}.attn1.to_q.weight", (c, c)), (f"{b}.attn1.to_k.weight", (c, c)), (f"{b}.attn1.to_v.weight", (c, c)),
+                (f"{b}.attn1.to_out.0.weight", (c, c)), (f"{b}.attn1.to_out.0.bias", (c,)),
+                (f"{b}.ff.net.0.proj.weight", (8 * c, c)), (f"{b}.ff.net.0.proj.bias", (8 * c,)),
+                (f"{b}.ff.net.2.weight", (c, 4 * c)), (f"{b}.ff.net.2.bias", (c,)),
+                (f"{b}.attn2.to_q.weight", (c, c)), (f"{b}.attn2.to_k.weight", (c, ctx)), (f"{b}.attn2.to_v.weight", (c, ctx)),
+                (f"{b}.attn2.to_out.0.weight", (c, c)), (f"{b}.attn2.to_out.0.bias", (c,)),
+                (f"{b}.norm2.weight", (c,)), (f"{b}.norm2.bias", (c,)), (f"{b}.norm1.weight", (c,)), (f"{b}.norm1.bias", (c,)),
+                (f"{b}.norm3.weight", (c,)), (f"{b}.norm3.bias", (c,))]
+        norms += [f"{b}.norm2.weight", f"{b}.norm1.weight", f"{b}.norm3.weight"]
+    out += [(f"{p}.proj_out.weight", (c, c, 1, 1)), (f"{p}.proj_out.bias", (c,))]
+    return norms
+
+
+def unet_names_shapes(cfg):
+    mc, emb, ctx = cfg["model_channels"], 4 * cfg["model_channels"], cfg["context_dim"]
+    out, norms = [], []
+    out += [("time_embed.0.weight", (emb, mc)), ("time_embed.0.bias", (emb,)), ("time_embed.2.weight", (emb, emb)), ("time_embed.2.bias", (emb,))]
+    out += [("input_blocks.0.0.weight", (mc, cfg["in_channels"], 3, 3)), ("input_blocks.0.0.bias", (mc,))]
+    chans = [mc]
+    ch, bi = mc, 1
+    td = list(cfg["transformer_depth"])
+    nlev = len(cfg["channel_mult"])
+    for lev in range(nlev):
+        cout = mc * cfg["channel_mult"][lev]
+        for _ in range(cfg["num_res_blocks"][lev]):
+            norms += _res(f"input_blocks.{bi}.0", ch, cout, emb, out)
+            ch = cout
+            d = td.pop(0)
+            if d > 0:
+                norms += _st(f"input_blocks.{bi}.1", ch, ctx, d, out)
+            chans.append(ch)
+            bi += 1
+        if lev != nlev - 1:
+            out += [(f"input_blocks.{bi}.0.op.weight", (ch, ch, 3, 3)), (f"input_blocks.{bi}.0.op.bias", (ch,))]
+            chans.append(ch)
+            bi += 1
+    norms += _res("middle_block.0", ch, ch, emb, out)
+    norms += _st("middle_block.1", ch, ctx, cfg["transformer_depth_middle"], out)
+    norms += _res("middle_block.2", ch, ch, emb, out)
+    tdo = list(cfg["transformer_depth_output"])
+    bo = 0
+    for lev in reversed(range(nlev)):
+        cout = mc * cfg["channel_mult"][lev]
+        for i in range(cfg["num_res_blocks"][lev] + 1):
+            cs = chans.pop()
+            norms += _res(f"output_blocks.{bo}.0", ch + cs, cout, emb, out)
+            ch = cout
+            d = tdo.pop()
+            j = 1
+            if d > 0:
+                norms += _st(f"output_blocks.{bo}.1", ch, ctx, d, out)
+                j = 2
+            if lev > 0 and i == cfg["num_res_blocks"][lev]:
+                out += [(f"output_blocks.{bo}.{j}.conv.weight", (ch, ch, 3, 3)), (f"output_blocks.{bo}.{j}.conv.bias", (ch,))]
+            bo += 1
+    out += [("out.0.weight", (ch,)), ("out.0.bias", (ch,)), ("out.2.weight", (cfg["out_channels"], ch, 3, 3)),
+            ("out.2.bias", (cfg["out_channels"],))]
+    norms.append("out.0.weight")
+    return out, norms
+
+
+def vae_decoder_names_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, out_ch=3):
+    out, norms = [], []
+
+    def res(p, cin, cout):
+        out.extend([(f"{p}.norm1.weight", (cin,)), (f"{p}.norm1.bias", (cin,)), (f"{p}.conv1.weight", (cout, cin, 3, 3)),
+                    (f"{p}.conv1.bias", (cout,)), (f"{p}.norm2.weight", (cout,)), (f"{p}.norm2.bias", (cout,)),
+                    (f"{p}.conv2.weight", (cout, cout, 3, 3)), (f"{p}.conv2.bias", (cout,))])
+        norms.extend([f"{p}.norm1.weight", f"{p}.norm2.weight"])
+        if cin != cout:
+            out.extend([(f"{p}.nin_shortcut.weight", (cout, cin, 1, 1)), (f"{p}.nin_shortcut.bias", (cout,))])
+    bi = ch * ch_mult[-1]
+    out += [("conv_in.weight", (bi, z_channels, 3, 3)), ("conv_in.bias", (bi,))]
+    res("mid.block_1", bi, bi)
+    out += [("mid.attn_1.norm.weight", (bi,)), ("mid.attn_1.norm.bias", (bi,))]
+    norms.append("mid.attn_1.norm.weight")
+    for n in ("q", "k", "v", "proj_out"):
+        out += [(f"mid.attn_1.{n}.weight", (bi, bi, 1, 1)), (f"mid.attn_1.{n}.bias", (bi,))]
+    res("mid.block_2", bi, bi)
+    # the decoder builds levels top-down but registers them with up.insert(0, ...): state_dict order is up.0 first
+    cins = {}
+    cur = bi
+    for lev in reversed(range(len(ch_mult))):
+        cins[lev] = cur
+        cur = ch * ch_mult[lev]
+    for lev in range(len(ch_mult)):
+        cin, cout = cins[lev], ch * ch_mult[lev]
+        for i in range(num_res_blocks + 1):
+            res(f"up.{lev}.block.{i}", cin, cout)
+            cin = cout
+        if lev != 0:
+            out += [(f"up.{lev}.upsample.conv.weight", (cout, cout, 3, 3)), (f"up.{lev}.upsample.conv.bias", (cout,))]
+    c0 = ch * ch_mult[0]
+    out += [("norm_out.weight", (c0,)), ("norm_out.bias", (c0,)), ("conv_out.weight", (out_ch, c0, 3, 3)), ("conv_out.bias", (out_ch,))]
+    norms.append("norm_out.weight")
+    return out, norms

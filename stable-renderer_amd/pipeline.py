@@ -1,0 +1,143 @@
+"""The render-then-diffuse frame loop, end to end on one GPU:
+
+  rasterise N views (sr_raster_draw)                       RenderManager.on_frame_run           renderManager.py:950-1043
+  -> EngineData (ids, masks, pooled + AdaIN'd noise)       RenderManager._save_frame_data       renderManager.py:877-948
+  -> CorrespondSampler (KSampler loop, UNet plan, CFG,     _nodes/samplers.py:128-201, nodes.py:1438-1495,
+     per-step latent overlap, K/V injection)               comfy/samplers.py:176-358, corresponder.py:188-376
+  -> VAE decode                                            comfy/sd.py:329-346
+  -> corresponder.finished -> CorrespondMap.update         corresponder.py:130-155, corrmap.py:578-736
+
+This is the body of the reference's bake call (DiffusionManager.SubmitPrompt with a bake workflow,
+diffusionManager.py:289-352) for a scene of the ``scripts/bake_ball.py`` kind; all stages stay in HBM."""
+import math
+
+import torch
+
+from . import ops as O
+from . import scene as S
+from .corrmap import CorrespondMap, IDMap
+from .corresponder import DefaultCorresponder, OverlapCorresponder
+from .sampling import DiffusionRunner
+from .types import EngineData, LATENT
+
+
+class BakeBallScene:
+    """scripts/bake_ball.py:19-62: camera (0,0.68,2.3) -> (0,0.68,0), sphere scale 0.70 with a diffuse texture, corr-map
+    proxy sphere scale 0.85 (k=6, texcoord ids, baking mode, TRANSPARENT queue), 1 degree of Y rotation per frame."""
+
+    def __init__(self, W=512, H=512, k=6, seed=0, device="cuda"):
+        self.W, self.H, self.k = W, H, k
+        self.camera = S.Camera((0, 0.68, 2.3), (0, 0.68, 0), fov=45.0, near=0.1, far=100.0)
+        self.sphere = S.Mesh.Sphere(32)
+        g = torch.Generator().manual_seed(seed)
+        self.noise_tex = torch.randn(512, 512, 4, generator=g).half().to(device)        # Texture.CreateNoiseTex (texture.py:507-568)
+        self.diffuse = torch.rand(64, 64, 4, generator=g).to(device)
+        self.diffuse[..., 3] = 1.0
+        self.corrmap = CorrespondMap(k=k, height=H, width=W, device=device)
+        self.sprite, self.material = 2, 2
+
+    def tasks(self, frame):
+        rot = S.rotate_y(float(frame))
+        at = S.translate((0, 0.68, 0))
+        m1 = S.matmul(at, S.matmul(rot, S.scale(0.70)))
+        m2 = S.matmul(at, S.matmul(rot, S.scale(0.85)))
+        return [
+            S.DrawTask(self.sphere, m1, sprite_id=1, material_id=1, render_mode=0, diffuse_tex=self.diffuse, order=999.7),
+            S.DrawTask(self.sphere, m2, sprite_id=self.sprite, material_id=self.material, render_mode=2, corrmap_k=self.k,
+                       use_texcoord_id=True, id_size=(self.W, self.H), noise_tex=self.noise_tex, order=2000.3),
+        ]
+
+
+class FramePipeline:
+    def __init__(self, unet, vae, scene, n_views=8, steps=20, cfg=8.0, sampler="ddim", scheduler="normal",
+                 corresponder=None, use_graph=True, bg_seed=1):
+        self.unet, self.vae, self.scene = unet, vae, scene
+        self.N, self.steps, self.cfg, self.sampler, self.scheduler = n_views, steps, cfg, sampler, scheduler
+        dev = unet.device
+        self.W, self.H = scene.W, scene.H
+        self.h, self.w = self.H // 8, self.W // 8
+        self.gbuf = S.GBuffer(self.W, self.H, device=dev)
+        self.corresponder = corresponder if corresponder is not None else OverlapCorresponder(
+            step_finished_inject_ratio=0.5, step_finished_stop_inject_timestep=500, update_corrmap_mode="first")
+        # the reference's OverlapCorresponder has no finished(); the bake (corr-map update) is DefaultCorresponder's.
+        # ignore_obj_mat_id_when_update=True is the reference option that avoids _update's double-gather IndexError on
+        # partially covered frames (corrmap.py:703/710; reproduced in corrmap.py of this package)
+        self.baker = DefaultCorresponder(update_corrmap_mode="first", ignore_obj_mat_id_when_update=True)
+        self.runner = DiffusionRunner(unet, n_views, self.h, self.w, cfg, use_graph=use_graph)
+        self.vplan = vae.build(n_views, self.h, self.w)
+        g = torch.Generator().manual_seed(bg_seed)
+        self.bg_noise = torch.randn(1, self.H, self.W, 4, generator=g).to(dev)                # RenderManager.GlobalBGNoise
+        # per-call EngineData accumulators (N,H,W,*) resident in HBM
+        self.ids = torch.zeros(n_views, self.H, self.W, 4, dtype=torch.int32, device=dev)
+        self.colors = torch.zeros(n_views, self.H, self.W, 3, dtype=torch.float16, device=dev)
+        self.masks = torch.zeros(n_views, self.H, self.W, dtype=torch.float16, device=dev)
+        self.noise = torch.zeros(n_views, 4, self.h, self.w, dtype=torch.float32, device=dev)
+        self.frame0 = 0
+
+    def set_prompt(self, positive, negative):
+        self.runner.set_conditioning(positive, negative)
+
+    def render_views(self):
+        """N consecutive frames -> EngineData (the per-frame part of _save_frame_data)."""
+        for i in range(self.N):
+            self.gbuf.render(self.scene.tasks(self.frame0 + i), self.scene.camera)
+            self.ids[i].copy_(self.gbuf.id)
+            self.colors[i].copy_(self.gbuf.color[..., :3])
+            alpha = self.gbuf.color[..., 3].contiguous()
+            self.masks[i].copy_(1.0 - alpha)
+            _, nz = O.noise_pool(self.gbuf.noise.unsqueeze(0), alpha.unsqueeze(0), self.bg_noise)
+            self.noise[i].copy_(nz[0])
+        self.frame0 += self.N
+        idm = IDMap(self.ids)
+        return EngineData(frame_indices=list(range(self.N)), color_maps=self.colors, id_maps=idm, masks=self.masks,
+                          noise_maps=LATENT(samples=torch.zeros_like(self.noise), noise=self.noise),
+                          correspond_maps={(self.scene.sprite, self.scene.material): self.scene.corrmap})
+
+    def diffuse(self, ed):
+        corr = self.corresponder
+        cb, n_rand = None, None
+        if isinstance(corr, OverlapCorresponder):
+            if self.sampler not in ("ddim", "ddpm"):
+                raise ValueError("OverlapCorresponder only works with ddim or ddpm sampler_name.")   # _nodes/samplers.py:163-164
+            n_rand = corr.pre_attn_inject_num_random_frames
+
+            def cb(ctx):
+                corr.step_finished(ed, ctx)
+        samples, inj = self.runner.sample(ed.noise_maps["noise"], self.steps, self.sampler, self.scheduler,
+                                          latent_image=ed.noise_maps["samples"], inject_n_rand=n_rand, step_callback=cb)
+        if isinstance(corr, OverlapCorresponder) and inj is not None:
+            corr._random_frame_indices = torch.tensor(inj)
+        return samples
+
+    def decode(self, samples):
+        self.vplan["z"].copy_(samples)
+        self.vplan["plan"].run()
+        return self.vplan["img"]                       # (N, H, W, 3) fp32 in [0,1]
+
+    def call(self):
+        """one bake call = N frames; returns the decoded frames"""
+        ed = self.render_views()
+        samples = self.diffuse(ed)
+        images = self.decode(samples)
+        self.baker.finished(ed, images)
+        return images
+
+
+def build_sd15_pipeline(dtype=torch.float16, n_views=8, steps=20, cfg=8.0, W=512, H=512, seed=0, unet_cfg=None,
+                        use_graph=True, vae_ch=128, device="cuda"):
+    """Random-init SD1.5-shaped UNet + VAE decoder (no checkpoints offline; synth.py) on the bake_ball scene."""
+    from . import synth
+    from .unet import UNet, SD15_CFG
+    from .vae import VAEDecoder
+    from .model_shapes import unet_names_shapes, vae_decoder_names_shapes
+    cfgu = dict(SD15_CFG if unet_cfg is None else unet_cfg)
+    ns, norms = unet_names_shapes(cfgu)
+    unet = UNet(synth.synth_state_dict(ns, seed=seed, norm_names=norms), cfgu, dtype=dtype, device=device)
+    vns, vnorms = vae_decoder_names_shapes(ch=vae_ch)
+    vae = VAEDecoder(synth.synth_state_dict(vns, seed=seed + 2, norm_names=vnorms), dtype=dtype, device=device)
+    scene = BakeBallScene(W, H, device=device)
+    pipe = FramePipeline(unet, vae, scene, n_views=n_views, steps=steps, cfg=cfg, use_graph=use_graph)
+    g = torch.Generator().manual_seed(seed + 11)
+    cd = cfgu["context_dim"]
+    pipe.set_prompt(torch.randn(1, 77, cd, generator=g), torch.randn(1, 77, cd, generator=g))
+    return pipe

@@ -9,7 +9,8 @@ from . import ops as O
 
 
 class Plan:
-    def __init__(self, op_list, keep):
+    def __init__(self, op_list, keep, op_flops=None):
+        self.op_flops = list(op_flops) if op_flops is not None else [0] * len(op_list)
         self.n = len(op_list)
         self.ops = (L.Op * max(self.n, 1))(*op_list)
         self._keep = keep                      # tensors referenced by raw pointers inside the ops
@@ -18,6 +19,11 @@ class Plan:
 
     def run(self):
         L.check(L.lib().sr_plan_run(self.ops, self.n, O.stream_ptr()))
+
+    def subset(self, kind):
+        """-> Plan holding only the ops of one kind (same buffers): used to time one kernel family in isolation"""
+        idx = [i for i in range(self.n) if self.ops[i].kind == kind]
+        return Plan([self.ops[i] for i in idx], self._keep, [self.op_flops[i] for i in idx])
 
     def capture(self, stream):
         """capture into a hipGraph on `stream` (a torch.cuda.Stream, not the default one)"""
@@ -44,6 +50,7 @@ class PlanBuilder:
     def __init__(self, device, dtype):
         self.device, self.dtype = device, dtype
         self.ops = []
+        self.op_flops = []
         self.keep = []
         self._gn_scratch = None
         self.flops = 0
@@ -61,6 +68,7 @@ class PlanBuilder:
         op.kind = kind
         setattr(op.u, field, args)
         self.ops.append(op)
+        self.op_flops.append(0)
 
     # ---- ops ------------------------------------------------------------------------------------------
     def igemm(self, a, w, out, B, H, W, C1, N, **kw):
@@ -68,7 +76,9 @@ class PlanBuilder:
         self._emit(L.OP_IGEMM, "igemm", O.igemm_args(a, w, out, B, H, W, C1, N, dtype=self.dtype, **kw))
         KH, st, up = kw.get("KH", 1), kw.get("stride", 1), kw.get("upsample", 0)
         Ho, Wo = (2 * H, 2 * W) if up else ((H + st - 1) // st, (W + st - 1) // st)
-        self.flops += 2 * B * Ho * Wo * N * KH * KH * (C1 + kw.get("C2", 0))
+        f = 2 * B * Ho * Wo * N * KH * KH * (C1 + kw.get("C2", 0))
+        self.flops += f
+        self.op_flops[-1] = f
 
     def groupnorm(self, x, gamma, beta, y, B, HW, C1, x2=None, C2=0, eps=1e-5, silu=False):
         need = L.lib().sr_groupnorm_scratch_floats(B, HW)
@@ -88,6 +98,7 @@ class PlanBuilder:
         self.hold(q, k, vt, o)
         self._emit(L.OP_ATTENTION, "attn", O.attention_args(q, k, vt, o, B, Bk, Tq, Tk, heads, d, ldt))
         self.flops += 4 * B * heads * Tq * Tk * d
+        self.op_flops[-1] = 4 * B * heads * Tq * Tk * d
 
     def nchw_to_nhwc(self, x, y, B, Cc, HW, Cpad, scale=1.0):
         self.hold(x, y)
@@ -123,6 +134,7 @@ class PlanBuilder:
 
     def take(self):
         """-> Plan of the ops emitted so far (the builder keeps collecting into a fresh list)"""
-        p = Plan(self.ops, list(self.keep))
+        p = Plan(self.ops, list(self.keep), self.op_flops)
         self.ops = []
+        self.op_flops = []
         return p

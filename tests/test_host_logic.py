@@ -1,0 +1,86 @@
+"""CPU tests of the host logic: schedules vs the reference goldens, checkpoint key enumeration, scene maths, the C-ABI
+library (loads, exports every symbol of include/sr_hip.h; no compute without a GPU)."""
+import json
+import os
+import re
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_model_key_enumeration_matches_reference_state_dicts():
+    from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes
+    from stable_renderer_amd.unet import SD15_CFG
+    for fn, cfg in (("unet_sd15_keys.json", SD15_CFG), ("unet_tiny_keys.json", dict(SD15_CFG, model_channels=64, context_dim=64))):
+        with open(os.path.join(GOLD, fn)) as f:
+            k = json.load(f)
+        ns, norms = unet_names_shapes(cfg)
+        assert [(n, list(s)) for n, s in ns] == [(n, list(s)) for n, s in k["names_shapes"]]
+        assert sorted(norms) == sorted(k["norm_names"])
+    with open(os.path.join(GOLD, "vae_dec_keys.json")) as f:
+        k = json.load(f)
+    ns, norms = vae_decoder_names_shapes()
+    assert [(n, list(s)) for n, s in ns] == [(n, list(s)) for n, s in k["names_shapes"]]
+    assert sorted(norms) == sorted(k["norm_names"])
+
+
+def test_schedules_match_reference():
+    from stable_renderer_amd import sampling as S
+    d = np.load(os.path.join(GOLD, "sampling.npz"))
+    ms = S.ModelSamplingDiscrete()
+    assert torch.allclose(ms.sigmas, torch.from_numpy(d["sigmas_table"]), rtol=1e-6)
+    for sch in S.SCHEDULER_NAMES:
+        for steps in (4, 20):
+            assert torch.allclose(S.calculate_sigmas_scheduler(ms, sch, steps), torch.from_numpy(d[f"{sch}_{steps}"]), rtol=2e-6, atol=1e-7)
+    for sch, steps, den in [("normal", 20, 1.0), ("normal", 20, 0.55), ("sgm_uniform", 4, 0.55), ("karras", 20, 0.7)]:
+        ks = S.KSampler(steps, "euler", sch, den)
+        assert torch.allclose(ks.sigmas, torch.from_numpy(d[f"ks_{sch}_{steps}_{int(den*100)}_sigmas"]), rtol=2e-6, atol=1e-7)
+        assert ks.timesteps == d[f"ks_{sch}_{steps}_{int(den*100)}_timesteps"].tolist()
+
+
+def test_library_exports_every_declared_symbol():
+    from stable_renderer_amd import _lib
+    L = _lib.lib()                       # raises if the .so is missing or a symbol of SYMBOLS is absent
+    hdr = open(os.path.join(ROOT, "include", "sr_hip.h")).read()
+    declared = set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sr_op", "sr_draw", "sr_gbuffer"}
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), name
+        assert name in _lib.SYMBOLS, f"{name} declared in the header but not bound"
+    assert L.sr_version() >= 100
+    assert L.sr_groupnorm_scratch_floats(2, 4096) == 2 * 64 * 64 * 2
+
+
+def test_no_cpu_fallback_without_library(monkeypatch):
+    from stable_renderer_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsr_hip.so")
+    try:
+        _lib.lib()
+        assert False, "must fail loudly"
+    except _lib.SrHipError as e:
+        assert "no CPU fallback" in str(e)
+
+
+def test_scene_math():
+    from stable_renderer_amd import scene as S
+    v = S.look_at((0, 0.68, 2.3), (0, 0.68, 0), (0, 1, 0))
+    p = S.perspective(np.radians(45.0), 1.0, 0.1, 100.0)
+    # a point 1.6 in front of the camera on the axis lands at NDC (0,0) with w = 1.6
+    pt = np.array([0, 0.68, 0.7, 1], np.float32)
+    eye = (v.T @ pt)
+    clip = (p.T @ eye)
+    assert np.allclose(eye[:3], [0, 0, -1.6], atol=1e-6) and abs(clip[3] - 1.6) < 1e-6 and abs(clip[0]) < 1e-6
+    m = S.matmul(S.translate((1, 2, 3)), S.scale(2.0))
+    assert np.allclose((m.T @ np.array([1, 1, 1, 1], np.float32))[:3], [3, 4, 5])
+    it = S.inverse_transpose(m)
+    assert np.allclose(it.T @ m.T.T, np.eye(4), atol=1e-6) or np.allclose(np.linalg.inv(m.T).T, it.T, atol=1e-6)
+    sp = S.Mesh.Sphere(32)
+    assert sp.positions.shape == (1089, 3) and sp.tris.shape == (2 * 32 * 32 - 2, 3)
+    assert sp.tris.max() < 1089 and (sp.tris % 33 != 32).all()          # seam column never referenced (mesh.py:555-558)
+    t = S.strip_to_triangles([0, 1, 2, 3])
+    assert t.tolist() == [[0, 1, 2], [2, 1, 3]]
