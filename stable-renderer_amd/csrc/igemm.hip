@@ -133,6 +133,85 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sr_igemm_args p, const
   const int N = p.N;
   if constexpr (!TRANS) {
     const int ldo = (p.act == 2) ? (N >> 1) : N;
+    const bool o32 = p.out_f32 || sizeof(T) == 4;
+    const int oes = o32 ? 4 : 2;                             // output element size
+    if ((ldo * oes) % 16 == 0) {
+      // Coalesced path: bias / time-embedding / activation in registers, then the wave's sub-tile goes through LDS
+      // (the staging buffers are free now) so that global stores -- and the residual loads -- are whole 16-byte
+      // chunks of contiguous rows instead of 4..8-byte pieces scattered over 16 rows per instruction.
+      constexpr int WCOLS = BN / WAVES_N;                    // columns of this wave's sub-tile before GEGLU
+      const int ocols = (p.act == 2) ? WCOLS / 2 : WCOLS;
+      const int rowb = ocols * oes + 16;                     // padded LDS row (bank spread, keeps 16-B alignment)
+      __syncthreads();                                       // every wave is done reading the staging tiles
+      char* wl = smem + wv * ((BM / WAVES_M) * rowb);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + pm0 + tm * 16 + c16;
+        const int b = (m < M) ? m / rpb : 0;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int n = n0 + qn0 + tn * 16 + 4 * g4;
+          float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
+          if (n < N) {                                       // N % 4 == 0 on this path
+            if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+            if (p.rowvec) { const float4 rv = *(const float4*)(p.rowvec + (int64_t)b * N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+          }
+          if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
+          else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
+          else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
+          char* dst = wl + (tm * 16 + c16) * rowb;
+          if (p.act == 2) {
+            const float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
+            const int col = tn * 8 + 2 * g4;
+            if (o32) *(float2*)(dst + col * 4) = make_float2(o0, o1);
+            else { h16x2 hv = {(_Float16)o0, (_Float16)o1}; *(h16x2*)(dst + col * 2) = hv; }
+          } else {
+            const int col = tn * 16 + 4 * g4;
+            if (o32) *(float4*)(dst + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            else { h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; *(h16x4*)(dst + col * 2) = hv; }
+          }
+        }
+      }
+      // read back row-wise (same wave wrote it: no block barrier needed, only the LDS write->read ordering)
+      __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+      const int cpr = ocols * oes / 16;                      // 16-B chunks per row
+      const int rpi = 64 / cpr;                              // rows per wave instruction
+      const int lr = lane / cpr, lc = lane - lr * cpr;
+      const int ncol0 = (p.act == 2) ? ((n0 + qn0) >> 1) : (n0 + qn0);
+      const int epc_o = 16 / oes;
+      for (int r0 = 0; r0 < BM / WAVES_M; r0 += rpi) {
+        const int row = r0 + lr;
+        if (lr >= rpi || row >= BM / WAVES_M) continue;
+        const int m = m0 + pm0 + row, ncol = ncol0 + lc * epc_o;
+        if (m >= M || ncol >= ldo) continue;
+        uint4 raw = *(const uint4*)(wl + row * rowb + lc * 16);
+        const int64_t oi = (int64_t)m * ldo + ncol;
+        if (p.residual) {
+          if constexpr (sizeof(T) == 2) {
+            if (o32) {                                     // fp32 out + fp16 residual: 4 values per 16-byte out chunk
+              float4 f = __builtin_bit_cast(float4, raw);
+              const h16x4 r4 = *(const h16x4*)((const _Float16*)p.residual + oi);
+              f.x += (float)r4[0]; f.y += (float)r4[1]; f.z += (float)r4[2]; f.w += (float)r4[3];
+              raw = __builtin_bit_cast(uint4, f);
+            } else {
+              const h16x8 rr = *(const h16x8*)((const _Float16*)p.residual + oi);
+              h16x8 hv = __builtin_bit_cast(h16x8, raw);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) hv[e] = (_Float16)((float)hv[e] + (float)rr[e]);
+              raw = __builtin_bit_cast(uint4, hv);
+            }
+          } else {
+            float4 f = __builtin_bit_cast(float4, raw);
+            const float4 rr = *(const float4*)((const float*)p.residual + oi);
+            f.x += rr.x; f.y += rr.y; f.z += rr.z; f.w += rr.w;
+            raw = __builtin_bit_cast(uint4, f);
+          }
+        }
+        *(uint4*)((char*)p.out + oi * oes) = raw;
+      }
+      return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + pm0 + tm * 16 + c16;
@@ -222,7 +301,9 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   // skip all-padding n-tiles
   const int NTv = (a.N + BN - 1) / BN;
   const int nwg = MT * NTv;
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int lds_stage = 2 * (BM + BN) * 128;
+  constexpr int lds_epi = 4 * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);   // fp32 output sub-tiles of the 4 waves
+  constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
   auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TRANS>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
@@ -237,6 +318,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int n128 = (a.N + 127) / 128, n64 = (a.N + 63) / 64;
   const int64_t wg_128x128 = (int64_t)((M + 127) / 128) * n128;
   const bool waste128 = (n128 * 128 - a.N) * 8 > a.N;          // >12.5% padded columns with BN=128
+  // (a 128x160 tile for N = 320 measured slower than five 64-wide tiles on MI355X: 487 vs 612 TF/s on the 3x3 conv)
   if (!waste128 && wg_128x128 >= 192) return launch<T, 128, 128, 2, 2, TRANS>(a, M, Ho, Wo, st);
   const int64_t wg_128x64 = (int64_t)((M + 127) / 128) * n64;
   if (wg_128x64 >= 192) return launch<T, 128, 64, 2, 2, TRANS>(a, M, Ho, Wo, st);

@@ -108,16 +108,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
   float* sh = sc + C;
   float* gm = sh + C;      // [groups] mean, [groups] rstd
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  if (tid < groups) {
-    double s = 0.0, q = 0.0;                       // fixed-order reduction of the partials
-    const float* pp = partials + ((int64_t)b * nchunk * groups + tid) * 2;
-    for (int i = 0; i < nchunk; ++i) { s += pp[(int64_t)i * groups * 2]; q += pp[(int64_t)i * groups * 2 + 1]; }
-    const double cnt = (double)HW * cpg;
-    const double mean = s / cnt;
-    double var = q / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    gm[tid] = (float)mean;
-    gm[groups + tid] = (float)(1.0 / sqrt(var + (double)eps));
+  // fixed-order reduction of this batch entry's partials, spread over the whole block: thread (g, part) sums every
+  // 8th chunk, then thread g adds the 8 parts in order (bit-reproducible, no serial latency chain)
+  {
+    float* red = gm + 2 * groups;                  // [8][groups][2]
+    const int g = tid & 31, part = tid >> 5;       // groups <= 32 on this path (asserted by the host), 8 parts
+    if (g < groups) {
+      float s = 0.f, q = 0.f;
+      const float* pp = partials + ((int64_t)b * nchunk * groups + g) * 2;
+      for (int i = part; i < nchunk; i += 8) { s += pp[(int64_t)i * groups * 2]; q += pp[(int64_t)i * groups * 2 + 1]; }
+      red[(part * groups + g) * 2] = s; red[(part * groups + g) * 2 + 1] = q;
+    }
+    __syncthreads();
+    if (tid < groups) {
+      double s = 0.0, q = 0.0;
+      for (int p8 = 0; p8 < 8; ++p8) { s += red[(p8 * groups + tid) * 2]; q += red[(p8 * groups + tid) * 2 + 1]; }
+      const double cnt = (double)HW * cpg;
+      const double mean = s / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      gm[tid] = (float)mean;
+      gm[groups + tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
@@ -205,7 +217,8 @@ extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
   if (a->C1 % epc || a->C2 % epc) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: channels must be multiples of %d", epc);
   if (a->C2 > 0 && !a->x2) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C2>0 without x2");
   const int nchunk = sr_cdiv(a->HW, GN_PIX_PER_CHUNK);
-  const size_t lds = (size_t)(2 * C + 2 * a->groups) * sizeof(float);
+  if (a->groups > 32) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: at most 32 groups");
+  const size_t lds = (size_t)(2 * C + 2 * a->groups + 16 * a->groups) * sizeof(float);
   if (lds > 64 * 1024) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C too large");
   hipStream_t st = sr_stream(stream);
   dim3 grid(nchunk, a->B);

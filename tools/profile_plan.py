@@ -1,0 +1,67 @@
+"""Per-op timing of a launch plan on the GPU (development tool): python tools/profile_plan.py [unet|vae] [f16|f32]"""
+import ctypes as C
+import os
+import sys
+from collections import defaultdict
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from stable_renderer_amd import _lib as L  # noqa: E402
+from stable_renderer_amd import ops as O  # noqa: E402
+from stable_renderer_amd.pipeline import build_sd15_pipeline  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "unet"
+dtype = torch.float16 if (len(sys.argv) < 3 or sys.argv[2] == "f16") else torch.float32
+pipe = build_sd15_pipeline(dtype=dtype, use_graph=False)
+if which == "unet":
+    p = pipe.runner._ensure_plan([3])
+    pipe.runner._load_ctx(p)
+    plan = p["step"]
+else:
+    plan = pipe.vplan["plan"]
+lib = L.lib()
+names = {1: "igemm", 2: "groupnorm", 3: "layernorm", 4: "attention", 5: "nchw2nhwc", 6: "nhwc2nchw", 7: "temb", 8: "silu", 9: "softmax"}
+agg = defaultdict(lambda: [0.0, 0, 0.0])
+plan.run()
+torch.cuda.synchronize()
+reps = 3
+for i in range(plan.n):
+    op = plan.ops[i]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    one = (L.Op * 1)(op)
+    lib.sr_plan_run(one, 1, O.stream_ptr())
+    e0.record()
+    for _ in range(reps):
+        lib.sr_plan_run(one, 1, O.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    k = op.kind
+    if k == 1:
+        a = op.u.igemm
+        sig = f"igemm B{a.B} {a.H}x{a.W} C{a.C1}+{a.C2} N{a.N} k{a.KH} s{a.stride} u{a.upsample} act{a.act} t{a.transpose_out}"
+    elif k == 2:
+        a = op.u.gn
+        sig = f"groupnorm B{a.B} HW{a.HW} C{a.C1}+{a.C2} silu{a.silu}"
+    elif k == 4:
+        a = op.u.attn
+        sig = f"attention B{a.B} Bk{a.Bk} Tq{a.Tq} Tk{a.Tk} h{a.heads} d{a.d}"
+    elif k == 3:
+        a = op.u.ln
+        sig = f"layernorm rows{a.rows} C{a.C}"
+    else:
+        sig = names.get(k, str(k))
+    agg[sig][0] += us
+    agg[sig][1] += 1
+    agg[sig][2] += plan.op_flops[i]
+tot = sum(v[0] for v in agg.values())
+print(f"total {tot/1e3:.2f} ms over {plan.n} ops")
+for sig, (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+    tf = fl / (us * 1e-6) / 1e12 if us > 0 else 0
+    print(f"{us/1e3:8.3f} ms {100*us/tot:5.1f}%  n={n:3d} avg {us/n:8.1f} us {tf:7.1f} TF/s  {sig}")
+bykind = defaultdict(float)
+for sig, (us, n, fl) in agg.items():
+    bykind[sig.split()[0]] += us
+print({k: round(v / 1e3, 2) for k, v in bykind.items()})
