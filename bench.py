@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print per-stage wall times of one extra (synchronised) call to stderr")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +95,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     frames = a.views * a.steps * world
+    if a.breakdown and rank == 0:
+        tm = {}
+        pipe.call(timings=tm)
+        print("stage breakdown (ms, synchronised): " + json.dumps({k: round(v, 2) for k, v in tm.items()}), file=sys.stderr)
     # ---- roofline of the dominant kernel (implicit-GEMM conv/linear, MFMA bound): algorithmic FLOPs of every igemm
     # launch of one UNet evaluation / their summed duration, measured with events on the stream they are launched on
     roof = None

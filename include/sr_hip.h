@@ -106,13 +106,17 @@ int sr_timestep_embedding(const float* t, void* y, int32_t B, int32_t dim, int32
 int sr_silu(const void* x, void* y, int64_t n, int32_t dtype, void* stream);
 int sr_cast(const void* x, int32_t src_dtype, void* y, int32_t dst_dtype, int64_t n, void* stream);
 int sr_softmax_rows(void* x, int32_t rows, int32_t cols, int32_t dtype, void* stream);   /* in place; VAE mid attention */
+/* y[j] = x[sel[j]] for j < nsel, rows of row_bytes bytes (multiple of 16); `sel` is a DEVICE int32 array read at run
+ * time, so a captured plan stays valid when the injected frame changes: random_k = k_context[_random_frame_indices]
+ * (OverlapCorresponder.pre_atten_inject, corresponder.py:207-214). */
+int sr_gather_rows(const void* x, const int32_t* sel, void* y, int32_t nsel, int64_t row_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Launch plan: a flat array of ops executed back-to-back on one stream by native code (the Python host
  * builds it once per (model, batch, resolution); no Python in the per-step path).  */
 typedef enum {
   SR_OP_IGEMM = 1, SR_OP_GROUPNORM = 2, SR_OP_LAYERNORM = 3, SR_OP_ATTENTION = 4, SR_OP_NCHW_TO_NHWC = 5,
-  SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9
+  SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9, SR_OP_GATHER_ROWS = 10
 } sr_op_kind;
 typedef struct {
   int32_t kind; int32_t pad_;
@@ -124,6 +128,7 @@ typedef struct {
     struct { const void* x; void* y; const float* per_batch_scale; int32_t B, C, HW, Cpad, dtype, ldc; float scale; } cvt;
     struct { const float* t; void* y; int32_t B, dim, dtype; } temb;
     struct { const void* x; void* y; int64_t n; int32_t dtype; int32_t rows, cols; } ew;
+    struct { const void* x; void* y; const int32_t* sel; int64_t row_bytes; int32_t nsel; } gather;
   } u;
 } sr_op;
 int sr_plan_run(const sr_op* host_ops, int32_t n_ops, void* stream);

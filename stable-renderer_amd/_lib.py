@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsr_hip.so")
 
 SR_F16, SR_F32 = 0, 1
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_TIMESTEP_EMBED, OP_SILU,
- OP_SOFTMAX_ROWS) = range(1, 10)
+ OP_SOFTMAX_ROWS, OP_GATHER_ROWS) = range(1, 11)
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -51,9 +51,13 @@ class _Ew(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("n", i64), ("dtype", i32), ("rows", i32), ("cols", i32)]
 
 
+class _Gather(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("sel", vp), ("row_bytes", i64), ("nsel", i32)]
+
+
 class _OpU(C.Union):
     _fields_ = [("igemm", IgemmArgs), ("gn", GroupNormArgs), ("attn", AttentionArgs), ("ln", _Ln), ("cvt", _Cvt),
-                ("temb", _Temb), ("ew", _Ew)]
+                ("temb", _Temb), ("ew", _Ew), ("gather", _Gather)]
 
 
 class Op(C.Structure):
@@ -91,6 +95,7 @@ SYMBOLS = {
     "sr_silu": (C.c_int, [vp, vp, i64, i32, vp]),
     "sr_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
     "sr_softmax_rows": (C.c_int, [vp, i32, i32, i32, vp]),
+    "sr_gather_rows": (C.c_int, [vp, vp, vp, i32, i64, vp]),
     "sr_plan_run": (C.c_int, [P(Op), i32, vp]),
     "sr_plan_capture": (C.c_int, [P(Op), i32, vp, P(vp)]),
     "sr_graph_launch": (C.c_int, [vp, vp]),

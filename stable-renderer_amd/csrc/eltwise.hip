@@ -77,6 +77,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, in
   for (int i = tid; i < cols; i += 256) sr_store_f(row + i, __expf(sr_load_f(row + i) - mx) * inv);
 }
 
+__global__ void gather_rows_kernel(const uint4* __restrict__ x, const int* __restrict__ sel, uint4* __restrict__ y, int nsel, int64_t row_chunks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)nsel * row_chunks) return;
+  const int j = (int)(i / row_chunks);
+  const int64_t c = i - (int64_t)j * row_chunks;
+  y[i] = x[(int64_t)sel[j] * row_chunks + c];
+}
+
 __global__ void eps_scale_kernel(const float* __restrict__ x, float* __restrict__ xin, int64_t n, int copies, float inv) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -186,6 +194,14 @@ extern "C" int sr_softmax_rows(void* x, int32_t rows, int32_t cols, int32_t dtyp
   if (dtype == SR_F16) hipLaunchKernelGGL(softmax_rows_kernel<_Float16>, dim3(rows), dim3(256), 0, sr_stream(stream), (_Float16*)x, cols);
   else hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(rows), dim3(256), 0, sr_stream(stream), (float*)x, cols);
   SR_CHECK_LAUNCH("sr_softmax_rows");
+  return SR_OK;
+}
+
+extern "C" int sr_gather_rows(const void* x, const int32_t* sel, void* y, int32_t nsel, int64_t row_bytes, void* stream) {
+  if (!x || !sel || !y || row_bytes % 16) SR_FAIL(SR_ERR_INVALID, "sr_gather_rows: bad args");
+  const int64_t rc = row_bytes / 16;
+  hipLaunchKernelGGL(gather_rows_kernel, g1((int64_t)nsel * rc), dim3(256), 0, sr_stream(stream), (const uint4*)x, sel, (uint4*)y, nsel, rc);
+  SR_CHECK_LAUNCH("sr_gather_rows");
   return SR_OK;
 }
 

@@ -10,7 +10,9 @@
 
 namespace {
 
-constexpr int GN_PIX_PER_CHUNK = 64;
+// pixels per workgroup: 64 for UNet-sized maps, grows with HW so that a batch entry never has more than 64 chunks
+// (every apply block re-reduces its batch entry's partials; 64 chunks keeps that at 16 KB of L2 reads)
+__host__ __device__ inline int gn_ppc(int HW) { const int p = (HW + 63) / 64; return p < 64 ? 64 : p; }
 
 template <typename T>
 __device__ __forceinline__ void load_chunk(const T* p, float (&v)[sr_traits<T>::EPC]) {
@@ -47,8 +49,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x1,
   const int nps = pp_ >= 1 ? pp_ : 1;               // pixel slices held in LDS
   float* chs = (float*)smem_raw;                    // [nps][C] per-channel sums
   float* chq = chs + nps * C;                       // [nps][C] per-channel sums of squares
-  const int p0 = chunk * GN_PIX_PER_CHUNK;
-  const int p1 = min(HW, p0 + GN_PIX_PER_CHUNK);
+  const int ppc = gn_ppc(HW);
+  const int p0 = chunk * ppc;
+  const int p1 = min(HW, p0 + ppc);
   const int pp = 256 / cpt;                        // pixels processed in parallel when cpt <= 256
   if (pp >= 1) {
     const int cc = tid % cpt, ps = tid / cpt;
@@ -138,8 +141,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
     sc[c] = a; sh[c] = beta[c] - gm[g] * a;
   }
   __syncthreads();
-  const int p0 = chunk * GN_PIX_PER_CHUNK;
-  const int p1 = min(HW, p0 + GN_PIX_PER_CHUNK);
+  const int ppc = gn_ppc(HW);
+  const int p0 = chunk * ppc;
+  const int p1 = min(HW, p0 + ppc);
   const int total = (p1 - p0) * cpt;
   for (int idx = tid; idx < total; idx += 256) {
     const int p = p0 + idx / cpt, cc = idx - (idx / cpt) * cpt;
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 }  // namespace
 
 extern "C" int64_t sr_groupnorm_scratch_floats(int32_t B, int32_t HW) {
-  return (int64_t)B * sr_cdiv(HW, GN_PIX_PER_CHUNK) * 64 * 2;
+  return (int64_t)B * sr_cdiv(HW, gn_ppc(HW)) * 64 * 2;
 }
 
 extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
@@ -216,7 +220,7 @@ extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
   if (a->groups <= 0 || a->groups > 64 || C % a->groups) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C=%d groups=%d", C, a->groups);
   if (a->C1 % epc || a->C2 % epc) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: channels must be multiples of %d", epc);
   if (a->C2 > 0 && !a->x2) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C2>0 without x2");
-  const int nchunk = sr_cdiv(a->HW, GN_PIX_PER_CHUNK);
+  const int nchunk = sr_cdiv(a->HW, gn_ppc(a->HW));
   if (a->groups > 32) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: at most 32 groups");
   const size_t lds = (size_t)(2 * C + 2 * a->groups + 16 * a->groups) * sizeof(float);
   if (lds > 64 * 1024) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C too large");

@@ -114,12 +114,25 @@ class FramePipeline:
         self.vplan["plan"].run()
         return self.vplan["img"]                       # (N, H, W, 3) fp32 in [0,1]
 
-    def call(self):
-        """one bake call = N frames; returns the decoded frames"""
+    def call(self, timings=None):
+        """one bake call = N frames; returns the decoded frames.  timings: optional dict filled with per-stage wall ms
+        (forces a device sync after every stage: diagnostics only)."""
+        import time
+
+        def mark(name, t0):
+            if timings is not None:
+                torch.cuda.synchronize()
+                timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+            return time.perf_counter()
+        t = time.perf_counter()
         ed = self.render_views()
+        t = mark("raster+engine_data", t)
         samples = self.diffuse(ed)
+        t = mark("sampling", t)
         images = self.decode(samples)
+        t = mark("vae_decode", t)
         self.baker.finished(ed, images)
+        mark("corrmap_update", t)
         return images
 
 

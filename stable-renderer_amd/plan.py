@@ -132,6 +132,12 @@ class PlanBuilder:
         a.x, a.y, a.n, a.dtype, a.rows, a.cols = O._p(x), O._p(x), x.numel(), O.DT[x.dtype], rows, cols
         self._emit(L.OP_SOFTMAX_ROWS, "ew", a)
 
+    def gather_rows(self, x, sel, y, nsel, row_bytes):
+        self.hold(x, sel, y)
+        a = L._Gather()
+        a.x, a.y, a.sel, a.row_bytes, a.nsel = O._p(x), O._p(y), O._p(sel), row_bytes, nsel
+        self._emit(L.OP_GATHER_ROWS, "gather", a)
+
     def take(self):
         """-> Plan of the ops emitted so far (the builder keeps collecting into a fresh list)"""
         p = Plan(self.ops, list(self.keep), self.op_flops)

@@ -127,11 +127,14 @@ class DiffusionRunner:
         self._stream = torch.cuda.Stream(device=dev) if use_graph else None
 
     def _ensure_plan(self, inject_idx):
-        key = None if inject_idx is None else tuple(int(i) for i in inject_idx)
+        """the plan depends only on HOW MANY frames are injected; which ones is a device tensor rewritten per run"""
+        key = None if inject_idx is None else len(inject_idx)
         if self._plan is None or self._inject != key:
-            self._plan = self.unet.build(self.N * self.copies, self.h, self.w, inject_idx=key, n_ctx=self.n_ctx)
+            self._plan = self.unet.build(self.N * self.copies, self.h, self.w, inject_idx=inject_idx, n_ctx=self.n_ctx)
             self._inject = key
             self._captured = False
+        if inject_idx is not None:
+            self._plan["inject"].copy_(torch.tensor([int(i) for i in inject_idx], dtype=torch.int32))
         return self._plan
 
     def set_conditioning(self, positive, negative):
@@ -197,9 +200,10 @@ class DiffusionRunner:
         if noise_fn is None:
             def noise_fn():
                 return torch.randn(tuple(self.x.shape), dtype=torch.float32).to(dev)    # default_noise_sampler (CPU x)
+        t_index = [int(t) for t in self.ms.timestep(sig[:-1])]          # ModelSamplingDiscrete.timestep, once per run
         for i in range(len(sig) - 1):
             s, sn = float(sig[i]), float(sig[i + 1])
-            eps = self.model_eps(p, s, int(self.ms.timestep(sig[i])))
+            eps = self.model_eps(p, s, t_index[i])
             O.cfg_denoise(self.x, eps, self.den, self.d if sampler in ("euler", "ddim") else None, self.copies, s, self.cfg_scale)
             if step_callback is not None:
                 step_callback(SamplingCallbackContext(self.x, i, self.den, len(sig) - 1, ks.timesteps, sig.tolist()))
