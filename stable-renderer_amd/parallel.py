@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of ONE overlapped view group: one process per GPU, views split contiguously across
+ranks, ``torch.distributed`` over RCCL/xGMI on GPUs (backend "nccl") or gloo in the CPU tests.
+
+Exchange points of the path (they exist only with OverlapCorresponder):
+  * per denoise step — the latent overlap needs every view's latent: all-gather of (n_local,4,h,w) fp32 (64 KiB per view at
+    512^2), then every rank runs the identical overlap step on the full batch (id maps are replicated, built once) and keeps
+    its own slice.  An all-gather of latents moves 80x fewer bytes than all-reducing a dense per-vertex sum table.
+  * end of call — corr-map 'first' priority is frame order, so decoded frames are gathered to rank 0 and applied in order.
+Independent view groups (bench.py --gpus N, weak scaling) need none of this: no data-path collective."""
+import torch
+import torch.distributed as dist
+
+
+class ViewShard:
+    def __init__(self, n_views, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if n_views % self.world:
+            raise ValueError(f"{n_views} views do not split over {self.world} ranks")
+        self.n_views, self.n_local = n_views, n_views // self.world
+        self.slice = slice(self.rank * self.n_local, (self.rank + 1) * self.n_local)
+
+    def gather_latents(self, x_local):
+        """(n_local,C,h,w) on every rank -> (N,C,h,w) on every rank, rank order = view order"""
+        if self.world == 1:
+            return x_local
+        x_local = x_local.contiguous()
+        full = torch.empty((self.n_views,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+        dist.all_gather_into_tensor(full, x_local, group=self.group) if x_local.is_cuda else \
+            dist.all_gather(list(full.split(self.n_local)), x_local, group=self.group)
+        return full
+
+    def overlap_step(self, x_local, step_fn):
+        """step_fn(full) mutates the full (N,C,h,w) latent in place (OverlapIndex.step on GPUs); every rank computes the
+        same result and writes back its own views."""
+        full = self.gather_latents(x_local)
+        full = full if full is not x_local else x_local
+        step_fn(full)
+        if full is not x_local:
+            x_local.copy_(full[self.slice])
+        return x_local
+
+    def gather_frames_to_rank0(self, frames_local):
+        """decoded frames (n_local,H,W,C) -> rank 0 gets (N,H,W,C) in frame order (ordered 'first' corr-map merge)"""
+        if self.world == 1:
+            return frames_local
+        frames_local = frames_local.contiguous()
+        out = [torch.empty_like(frames_local) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(frames_local, out, dst=0, group=self.group)
+        return torch.cat(out, 0) if self.rank == 0 else None
+
+
+def timed_max_over_ranks(seconds, device):
+    """bench helper: MAX over ranks of a wall time"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
