@@ -1,0 +1,179 @@
+"""Stable-rendering node surface (the drop-in boundary of SURVEY.md §8b): classes with the reference's names and
+``__call__`` signatures (comfyUI/stable_rendering/_nodes/{data,samplers}.py, comfyUI/nodes.py VAEDecode/custom_ksampler),
+executing on the HIP path.  The node *registration* machinery (AdvancedNodeBase -> ComfyUI web UI, node_base.py:179-686) is
+UI plumbing and out of scope; a graph executor only needs these callables."""
+from functools import partial
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from .corrmap import CorrespondMap
+from .corresponder import DefaultCorresponder as _DefaultCorresponder
+from .corresponder import OverlapCorresponder as _OverlapCorresponder
+from .sampling import DiffusionRunner
+from .types import EngineData, InferenceOutput, LATENT
+
+
+class StableRenderingNode:
+    NAMESPACE = "StableRendering"
+    Category = "stable-rendering"
+
+
+class MODEL:
+    """What CheckpointLoaderSimple hands to samplers here: a HIP UNet (+ lazily built runners keyed by batch/shape)."""
+
+    def __init__(self, unet):
+        self.unet = unet
+        self._runners = {}
+
+    def runner(self, N, h, w, cfg, use_graph=True):
+        key = (N, h, w, float(cfg), use_graph)
+        if key not in self._runners:
+            self._runners[key] = DiffusionRunner(self.unet, N, h, w, cfg, use_graph=use_graph)
+        return self._runners[key]
+
+
+class EngineDataNode(StableRenderingNode):
+    """_nodes/data.py:36-63: unpack the hidden EngineData into its 11 outputs."""
+
+    def __call__(self, engine_data: EngineData):
+        return (engine_data.color_maps, engine_data.id_maps, engine_data.pos_maps, engine_data.normal_maps,
+                engine_data.depth_maps, engine_data.canny_maps, engine_data.noise_maps, engine_data.masks,
+                engine_data.correspond_maps, engine_data.sprite_infos, engine_data.env_prompts)
+
+
+class VirtualEngineDataNode(StableRenderingNode):
+    """_nodes/data.py:71-105: build EngineData when running a graph without the engine."""
+    PriorNode = True
+
+    def __call__(self, color_maps=None, id_maps=None, pos_maps=None, normal_maps=None, depth_maps=None, canny_maps=None,
+                 noise_maps=None, masks=None, correspond_maps=None, sprites=None, env_prompt=None) -> EngineData:
+        n = len(id_maps) if id_maps is not None else (0 if color_maps is None else len(color_maps))
+        return EngineData(frame_indices=list(range(n)), color_maps=color_maps, id_maps=id_maps, pos_maps=pos_maps,
+                          normal_maps=normal_maps, depth_maps=depth_maps, canny_maps=canny_maps, noise_maps=noise_maps,
+                          masks=masks, correspond_maps=correspond_maps, sprite_infos=sprites, env_prompts=env_prompt)
+
+
+class EmptyCorrMaps(StableRenderingNode):
+    """_nodes/data.py:10-25"""
+
+    def __call__(self, k: int = 3, width: int = 512, height: int = 512, create_count: int = 1):
+        return {(i + 1, i + 1): CorrespondMap(k=k, width=width, height=height) for i in range(create_count)}
+
+
+class InferenceOutputNode(StableRenderingNode):
+    """_nodes/data.py:107-139"""
+    IsOutputNode = True
+    Unique = True
+
+    def __call__(self, colorImg, context=None) -> InferenceOutput:
+        out = InferenceOutput(colorImg)
+        if context is not None:
+            context.final_output = out
+        return out
+
+
+class DefaultCorresponder(StableRenderingNode):
+    """_nodes/samplers.py:20-68 -> (Corresponder, VAEDecodeCallback)"""
+    Category = "sampling"
+
+    def __call__(self, engine_data: EngineData, update_corrmap: bool = True, update_mode='first_avg',
+                 post_attn_inject_ratio: float = 0.6) -> Tuple[object, Callable]:
+        c = _DefaultCorresponder(update_corrmap=update_corrmap, update_corrmap_mode=update_mode,
+                                 post_attn_inject_ratio=post_attn_inject_ratio)
+        return c, partial(c.finished, engine_data)
+
+
+class OverlapCorresponder(StableRenderingNode):
+    """_nodes/samplers.py:71-125; the reference's OverlapCorresponder has no ``finished`` -> do-nothing VAE callback"""
+    Category = "sampling"
+
+    def __call__(self, engine_data: EngineData, update_corrmap: bool = True, update_mode='first_avg',
+                 pre_attn_inject_num_of_random_frames: int = 1, post_attn_inject_ratio: float = 0.6,
+                 step_finished_inject_ratio: float = 0.5, step_finished_stop_inject_timestep: int = 500):
+        c = _OverlapCorresponder(update_corrmap=update_corrmap, update_corrmap_mode=update_mode,
+                                 pre_attn_inject_num_random_frames=pre_attn_inject_num_of_random_frames,
+                                 post_attn_inject_ratio=post_attn_inject_ratio,
+                                 step_finished_inject_ratio=step_finished_inject_ratio,
+                                 step_finished_stop_inject_timestep=step_finished_stop_inject_timestep)
+        if hasattr(c, "finished"):
+            return c, partial(c.finished, engine_data)
+        return c, (lambda *a, **k: None)
+
+
+def custom_ksampler(model: MODEL, seed, steps, cfg, sampler_name, scheduler, positive, negative, latent, denoise=1.0,
+                    noise_option='random', callbacks=None, engine_data=None, corresponder=None, **kwargs):
+    """comfyUI/nodes.py:1438-1495.  positive / negative: (1|N, 77, ctx) embeddings (conditioning lists are unwrapped by the
+    caller).  ``engine_data`` / ``corresponder`` reach the attention blocks through the plan (K/V injection)."""
+    latent_image = latent["samples"]
+    N, _, h, w = latent_image.shape
+    if noise_option == 'disable':
+        noise = torch.zeros_like(latent_image)
+    elif noise_option == 'incoming' and "noise" in latent:
+        noise = latent["noise"]
+    elif noise_option in ('random', 'incoming'):
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 32, (1,)).item())
+        g = torch.manual_seed(seed)                                   # comfy/sample.py:19-28 prepare_noise
+        noise = torch.randn(latent_image.size(), dtype=latent_image.dtype, generator=g, device="cpu")
+    else:
+        raise ValueError(f"Invalid noise option: {noise_option}")
+    run = model.runner(N, h, w, cfg)
+    run.set_conditioning(positive, negative)
+    n_rand = None
+    if corresponder is not None and engine_data is not None and isinstance(corresponder, _OverlapCorresponder):
+        n_rand = corresponder.pre_attn_inject_num_random_frames
+    cb = None
+    if callbacks:
+        def cb(ctx):
+            for c in callbacks:
+                c(ctx)
+    samples, inj = run.sample(noise, steps, sampler_name, scheduler, denoise=denoise, latent_image=latent_image, seed=seed,
+                              inject_n_rand=n_rand, step_callback=cb)
+    if inj is not None and corresponder is not None:
+        corresponder._random_frame_indices = torch.tensor(inj)
+    out = LATENT(latent)
+    out["samples"] = samples
+    return (out,)
+
+
+class CorrespondSampler(StableRenderingNode):
+    """_nodes/samplers.py:128-201"""
+    Category = "sampling"
+
+    def __call__(self, model: MODEL, positive, negative, corresponder, engine_data: EngineData, latent: Optional[LATENT] = None,
+                 steps: int = 20, cfg: float = 8.0, sampler_name="euler", scheduler="normal", denoise: float = 1.0) -> LATENT:
+        if isinstance(corresponder, _OverlapCorresponder) and sampler_name not in ['ddim', 'ddpm']:
+            raise ValueError("OverlapCorresponder only works with ddim or ddpm sampler_name.")
+        if hasattr(corresponder, 'prepare'):
+            corresponder.prepare(engine_data)
+        callbacks = []
+        if hasattr(corresponder, "step_finished"):
+            callbacks = [partial(corresponder.step_finished, engine_data)]
+        if latent is None:
+            if engine_data is None:
+                raise ValueError("Input latent is None and engine_data is also None.")
+            latent = engine_data.noise_maps
+        return custom_ksampler(model=model, seed=None, steps=steps, cfg=cfg, sampler_name=sampler_name, scheduler=scheduler,
+                               positive=positive, negative=negative, latent=latent, denoise=denoise, noise_option='incoming',
+                               engine_data=engine_data, corresponder=corresponder, callbacks=callbacks)[0]
+
+
+class VAEDecode:
+    """comfyUI/nodes.py:287-303 (with the reference's ``callback`` hook)"""
+
+    def __init__(self):
+        self._plans = {}
+
+    def decode(self, vae, samples, callback=None):
+        z = samples["samples"]
+        key = tuple(z.shape)
+        if key not in self._plans:
+            self._plans[key] = vae.build(z.shape[0], z.shape[2], z.shape[3])
+        p = self._plans[key]
+        p["z"].copy_(z)
+        p["plan"].run()
+        images = p["img"]
+        if callback is not None:
+            callback(images)
+        return (images,)
