@@ -41,6 +41,19 @@ __device__ __forceinline__ void sr_glds16(const void* gsrc, void* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Same transfer issued from inline asm: hipcc then does NOT see a pending LDS write, so it does not drain the whole
+// pipeline (s_waitcnt vmcnt(0)) in front of the next ds_read; the caller owns the ordering: counted s_waitcnt vmcnt(N)
+// for the stage it is about to read, then a raw s_barrier.  M0 (LDS base of the wave) is saved/restored inside the
+// statement because it is compiler-reserved.  lds_addr must be wave-uniform.
+__device__ __forceinline__ void sr_glds16_asm(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned sr_lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 __device__ __forceinline__ float sr_silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sr_gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
