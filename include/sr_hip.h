@@ -110,13 +110,15 @@ int sr_softmax_rows(void* x, int32_t rows, int32_t cols, int32_t dtype, void* st
  * time, so a captured plan stays valid when the injected frame changes: random_k = k_context[_random_frame_indices]
  * (OverlapCorresponder.pre_atten_inject, corresponder.py:207-214). */
 int sr_gather_rows(const void* x, const int32_t* sel, void* y, int32_t nsel, int64_t row_bytes, void* stream);
+/* y = a + s*b (dtype tensors): apply_control (openaimodel.py:374-386), guided-hint add (cldm.py:297-300) */
+int sr_add_scaled(const void* a, const void* b, void* y, int64_t n, float s, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Launch plan: a flat array of ops executed back-to-back on one stream by native code (the Python host
  * builds it once per (model, batch, resolution); no Python in the per-step path).  */
 typedef enum {
   SR_OP_IGEMM = 1, SR_OP_GROUPNORM = 2, SR_OP_LAYERNORM = 3, SR_OP_ATTENTION = 4, SR_OP_NCHW_TO_NHWC = 5,
-  SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9, SR_OP_GATHER_ROWS = 10
+  SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9, SR_OP_GATHER_ROWS = 10, SR_OP_ADD_SCALED = 11
 } sr_op_kind;
 typedef struct {
   int32_t kind; int32_t pad_;
@@ -129,6 +131,7 @@ typedef struct {
     struct { const float* t; void* y; int32_t B, dim, dtype; } temb;
     struct { const void* x; void* y; int64_t n; int32_t dtype; int32_t rows, cols; } ew;
     struct { const void* x; void* y; const int32_t* sel; int64_t row_bytes; int32_t nsel; } gather;
+    struct { const void* a; const void* b; void* y; int64_t n; float s; int32_t dtype; } add;
   } u;
 } sr_op;
 int sr_plan_run(const sr_op* host_ops, int32_t n_ops, void* stream);

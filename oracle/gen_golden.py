@@ -470,9 +470,51 @@ def sec_e2e():
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     save("e2e_tiny", **out)
 
+def sec_controlnet():
+    """cldm.ControlNet.forward + control_merge + UNetModel.forward(control=...) on the tiny topology"""
+    import comfy.ldm.modules.attention as att
+    att.optimized_attention = att.attention_basic
+    import comfy.cldm.cldm as cldm
+    import comfy.ops
+    cfg = {k: v for k, v in TINY.items() if k not in ("out_channels", "transformer_depth_output")}
+    with torch.no_grad():
+        cn = cldm.ControlNet(hint_channels=3, operations=comfy.ops.disable_weight_init, **cfg)
+        cn.eval()
+        ns, norm = synth.fill_module_(cn, seed=5)
+        _jdump({"names_shapes": ns, "norm_names": norm}, os.path.join(GOLD, "controlnet_tiny_keys.json"))
+        unet, _, _ = build_unet(TINY, seed=1)
+        x = rnd(1, 2, 4, 16, 16)
+        t = torch.tensor([500.0, 500.0])
+        ctx = rnd(2, 2, 77, 64)
+        hint = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(3))
+        outs = cn(x=x, hint=hint, timesteps=t, context=ctx)
+        strength = 0.8
+        control = {"input": [], "middle": [outs[-1].clone() * strength], "output": [o.clone() * strength for o in outs[:-1]]}
+        y = unet(x, t, context=ctx, control=control, transformer_options={})
+        save("controlnet_tiny", x=x, t=t, ctx=ctx, hint=hint, y=y, mid=outs[-1], out0=outs[0], out11=outs[11])
+
+
+def sec_dump():
+    """CorrespondMap.dump / Load round trip by the reference (corrmap.py:738-872): the dumped directory itself is the
+    fixture (tests/golden/corrmap_dump/*), plus the tensors that went in and came back."""
+    import shutil
+    cm = R.import_corrmap()
+    m = cm.CorrespondMap(name="gold", k=2, height=8, width=8)
+    g = torch.Generator().manual_seed(4)
+    m._values = torch.rand(4, 64, 4, generator=g).half()
+    m._writtens = torch.rand(4, 64, generator=g) > 0.5
+    out = os.path.join(GOLD, "corrmap_dump")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out, exist_ok=True)
+    with quiet():
+        p = m.dump(out, name="gold")       # (force=True leaves real_path unset in the reference -> TypeError)
+        m2 = cm.CorrespondMap.Load(p)
+    save("corrmap_dump_io", values_in=m._values, writtens_in=m._writtens, values_back=m2._values, writtens_back=m2._writtens)
+
+
 
 SECTIONS = dict(math=sec_math, idmap=sec_idmap, overlap=sec_overlap, corrmap=sec_corrmap, noisepool=sec_noisepool,
-                sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e)
+                sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet)
 
 if __name__ == "__main__":
     todo = _ARGV or list(SECTIONS)

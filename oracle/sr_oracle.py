@@ -506,3 +506,43 @@ def sample_frames(sd, cfg, noise, pos, neg, ids, steps, cfg_scale, sampler, sche
 
     out = sample_loop(denoise_fn, x, sig, sampler, cb)
     return out / LATENT_SCALE, state["idx"]                 # process_latent_out (samplers.py:933)
+
+
+# ------------------------------------------------------------------------------------------------------
+# ControlNet (comfy/cldm/cldm.py:284-311) + control_merge (comfy/controlnet.py:95-141)
+def controlnet_forward(sd, cfg, x, hint, t, ctx, strength=1.0):
+    """-> dict(output=[12 tensors], middle=[1 tensor]) as consumed by unet_forward(control=...)"""
+    mc, heads = cfg["model_channels"], cfg["num_heads"]
+    emb = timestep_embedding(t, mc)
+    emb = F.linear(F.silu(F.linear(emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])),
+                   sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    g = hint
+    for i, stride in ((0, 1), (2, 1), (4, 2), (6, 1), (8, 2), (10, 1), (12, 2), (14, 1)):
+        g = F.conv2d(g, sd[f"input_hint_block.{i}.weight"], sd[f"input_hint_block.{i}.bias"], stride=stride, padding=1)
+        if i != 14:
+            g = F.silu(g)
+    outs = []
+
+    def zc(i, h):
+        return F.conv2d(h, sd[f"zero_convs.{i}.0.weight"], sd[f"zero_convs.{i}.0.bias"])
+    h = F.conv2d(x, sd["input_blocks.0.0.weight"], sd["input_blocks.0.0.bias"], padding=1) + g
+    outs.append(zc(0, h))
+    td = list(cfg["transformer_depth"])
+    bi, nlev = 1, len(cfg["channel_mult"])
+    for lev in range(nlev):
+        for _ in range(cfg["num_res_blocks"][lev]):
+            h = _resblock(sd, f"input_blocks.{bi}.0", h, emb)
+            depth = td.pop(0)
+            if depth > 0:
+                h = _stransformer(sd, f"input_blocks.{bi}.1", h, ctx, heads, depth, None)
+            outs.append(zc(bi, h))
+            bi += 1
+        if lev != nlev - 1:
+            h = F.conv2d(h, sd[f"input_blocks.{bi}.0.op.weight"], sd[f"input_blocks.{bi}.0.op.bias"], stride=2, padding=1)
+            outs.append(zc(bi, h))
+            bi += 1
+    h = _resblock(sd, "middle_block.0", h, emb)
+    h = _stransformer(sd, "middle_block.1", h, ctx, heads, cfg["transformer_depth_middle"], None)
+    h = _resblock(sd, "middle_block.2", h, emb)
+    mid = F.conv2d(h, sd["middle_block_out.0.weight"], sd["middle_block_out.0.bias"])
+    return {"output": [o * strength for o in outs], "middle": [mid * strength]}

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsr_hip.so")
 
 SR_F16, SR_F32 = 0, 1
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_TIMESTEP_EMBED, OP_SILU,
- OP_SOFTMAX_ROWS, OP_GATHER_ROWS) = range(1, 11)
+ OP_SOFTMAX_ROWS, OP_GATHER_ROWS, OP_ADD_SCALED) = range(1, 12)
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -55,9 +55,13 @@ class _Gather(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("sel", vp), ("row_bytes", i64), ("nsel", i32)]
 
 
+class _Add(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("y", vp), ("n", i64), ("s", f32), ("dtype", i32)]
+
+
 class _OpU(C.Union):
     _fields_ = [("igemm", IgemmArgs), ("gn", GroupNormArgs), ("attn", AttentionArgs), ("ln", _Ln), ("cvt", _Cvt),
-                ("temb", _Temb), ("ew", _Ew), ("gather", _Gather)]
+                ("temb", _Temb), ("ew", _Ew), ("gather", _Gather), ("add", _Add)]
 
 
 class Op(C.Structure):
@@ -96,6 +100,7 @@ SYMBOLS = {
     "sr_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
     "sr_softmax_rows": (C.c_int, [vp, i32, i32, i32, vp]),
     "sr_gather_rows": (C.c_int, [vp, vp, vp, i32, i64, vp]),
+    "sr_add_scaled": (C.c_int, [vp, vp, vp, i64, f32, i32, vp]),
     "sr_plan_run": (C.c_int, [P(Op), i32, vp]),
     "sr_plan_capture": (C.c_int, [P(Op), i32, vp, P(vp)]),
     "sr_graph_launch": (C.c_int, [vp, vp]),

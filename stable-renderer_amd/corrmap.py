@@ -1,8 +1,13 @@
 """IDMap / CorrespondMap with the reference's names and semantics (engine/static/corrmap.py:48-886), backed by HIP
 kernels.  Tensors live in HBM; the only host work is argument normalisation and the error behaviour the reference
 exhibits (IndexError on out-of-range ids, the double-gather quirk of ``_update``)."""
+import json
+import os
+import re
+import zipfile
 from typing import Literal, Optional
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -54,6 +59,33 @@ class IDMap:
     def width(self):
         return self.tensor.shape[-1]
 
+    @classmethod
+    def from_directory(cls, directory, frame_start=None, num_frames=None, use_frame_indices_from_filename=True, device="cuda"):
+        """corrmap.py:138-198: stack ``*.npy`` id maps of a dump directory (sorted by the number in the file name)."""
+        assert os.path.exists(directory)
+        frame_start = frame_start or 0
+
+        def idx_of(name, default):
+            m = re.findall(r"\d+", os.path.splitext(name)[0])
+            return int(m[-1]) if m else default
+        names = [f for f in os.listdir(directory) if f.endswith(".npy")]
+        names = sorted(names, key=lambda n: idx_of(n, names.index(n)))
+        frame_indices = [idx_of(n, -1) for n in names] if use_frame_indices_from_filename else list(range(len(names)))
+        num_frames = num_frames or len(frame_indices)
+        frame_indices = frame_indices[frame_start: frame_start + num_frames]
+        assert all(i != -1 for i in frame_indices), "Illegal filename(s) found."
+        ts = []
+        for n in names[frame_start: frame_start + num_frames]:
+            t = torch.from_numpy(np.load(os.path.join(directory, n))).squeeze()
+            if t.dim() != 3 or not (t.shape[-1] == 4 or t.shape[1] == 4):
+                raise ValueError(f"Invalid id tensor shape: {t.shape}.")
+            ts.append(t)
+        if not ts:
+            raise ValueError("No valid id data found.")
+        if any(t.shape != ts[0].shape for t in ts):
+            raise ValueError("Tensor data has inconsistent shapes.")
+        return cls(torch.stack(ts, 0).to(device), frame_indices=frame_indices)
+
     def overlap_index(self, lh, lw):
         """cached device structure replacing ``create_vertex_screen_info`` (corrmap.py:220-280) + per-step unique"""
         key = (lh, lw)
@@ -88,6 +120,63 @@ class CorrespondMap:
     @property
     def writtens(self):
         return self._writtens.bool()
+
+    # ---- on-disk format of the reference (corrmap.py:738-872): k*k PNGs + "<i>_written.png" + meta.json ----------------
+    def get_map(self, i):
+        return self._values[i].view(self.height, self.width, self.channel_count)
+
+    def get_written_flag_map(self, i):
+        return self._writtens[i].view(self.height, self.width)
+
+    def dump(self, path, name=None, zip=False, force=False):
+        from PIL import Image
+        name = name or self.name or "corrmap"
+        real_name, suffix = name, ('.zip' if zip else '')
+        if not force:
+            count = 1
+            while os.path.exists(os.path.join(path, real_name + suffix)):
+                real_name = f"{name}_{count}"
+                count += 1
+        work = os.path.join(path, real_name + ("_tmp" if zip else ""))
+        os.makedirs(work, exist_ok=True)
+        files = []
+        for i in range(self.k * self.k):
+            img = 255. * self.get_map(i).cpu().numpy()            # fp16 numpy product, as the reference (rounds in fp16)
+            Image.fromarray(np.clip(img, 0, 255).astype(np.uint8), mode='RGBA').save(os.path.join(work, f"{i}.png"))
+            wr = 255.0 * self.get_written_flag_map(i).float().cpu().numpy()
+            Image.fromarray(np.clip(wr, 0, 255).astype(np.uint8), mode='L').save(os.path.join(work, f"{i}_written.png"))
+            files += [f"{i}.png", f"{i}_written.png"]
+        with open(os.path.join(work, 'meta.json'), 'w') as f:
+            json.dump({"k": self.k, "height": self.height, "width": self.width, "channel_count": self.channel_count, "name": name}, f)
+        files.append('meta.json')
+        if not zip:
+            return work
+        real_path = os.path.join(path, real_name + suffix)
+        with zipfile.ZipFile(real_path, 'w') as z:
+            for fn in files:
+                z.write(os.path.join(work, fn), fn)
+                os.remove(os.path.join(work, fn))
+        os.rmdir(work)
+        return real_path
+
+    @classmethod
+    def Load(cls, path, name=None, device="cuda"):
+        import io
+        from PIL import Image
+        if os.path.isfile(path):
+            z = zipfile.ZipFile(path, 'r')
+            rd = lambda fn: io.BytesIO(z.read(fn))
+        else:
+            rd = lambda fn: open(os.path.join(path, fn), 'rb')
+        meta = json.load(rd('meta.json'))
+        m = cls(name=name or meta['name'], k=meta['k'], height=meta['height'], width=meta['width'],
+                channel_count=meta['channel_count'], device=device)
+        for i in range(m.k * m.k):
+            img = torch.tensor(np.array(Image.open(rd(f"{i}.png"))), dtype=torch.float32) / 255.
+            m._values[i] = img.view(-1, m.channel_count).to(m._values.dtype).to(m.device)
+            wr = torch.tensor(np.array(Image.open(rd(f"{i}_written.png"))), dtype=torch.float32) / 255.
+            m._writtens[i] = wr.bool().view(-1).to(torch.uint8).to(m.device)
+        return m
 
     def update(self, color_frames, id_maps, spriteID=None, materialID=None, mode: UpdateMode = 'first_avg', masks=None,
                inverse_masks=False, ignore_obj_mat_id=False):

@@ -77,6 +77,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, in
   for (int i = tid; i < cols; i += 256) sr_store_f(row + i, __expf(sr_load_f(row + i) - mx) * inv);
 }
 
+template <typename T>
+__global__ void add_scaled_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n, float s) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sr_store_f(y + i, sr_load_f(a + i) + s * sr_load_f(b + i));
+}
+
 __global__ void gather_rows_kernel(const uint4* __restrict__ x, const int* __restrict__ sel, uint4* __restrict__ y, int nsel, int64_t row_chunks) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)nsel * row_chunks) return;
@@ -194,6 +200,14 @@ extern "C" int sr_softmax_rows(void* x, int32_t rows, int32_t cols, int32_t dtyp
   if (dtype == SR_F16) hipLaunchKernelGGL(softmax_rows_kernel<_Float16>, dim3(rows), dim3(256), 0, sr_stream(stream), (_Float16*)x, cols);
   else hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(rows), dim3(256), 0, sr_stream(stream), (float*)x, cols);
   SR_CHECK_LAUNCH("sr_softmax_rows");
+  return SR_OK;
+}
+
+extern "C" int sr_add_scaled(const void* a, const void* b, void* y, int64_t n, float s, int32_t dtype, void* stream) {
+  if (!a || !b || !y) SR_FAIL(SR_ERR_INVALID, "sr_add_scaled: null");
+  if (dtype == SR_F16) hipLaunchKernelGGL(add_scaled_kernel<_Float16>, g1(n), dim3(256), 0, sr_stream(stream), (const _Float16*)a, (const _Float16*)b, (_Float16*)y, n, s);
+  else hipLaunchKernelGGL(add_scaled_kernel<float>, g1(n), dim3(256), 0, sr_stream(stream), (const float*)a, (const float*)b, (float*)y, n, s);
+  SR_CHECK_LAUNCH("sr_add_scaled");
   return SR_OK;
 }
 

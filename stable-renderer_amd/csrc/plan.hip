@@ -20,6 +20,7 @@ static int run_op(const sr_op& op, void* stream) {
       return sr_timestep_embedding(op.u.temb.t, op.u.temb.y, op.u.temb.B, op.u.temb.dim, op.u.temb.dtype, stream);
     case SR_OP_SILU: return sr_silu(op.u.ew.x, op.u.ew.y, op.u.ew.n, op.u.ew.dtype, stream);
     case SR_OP_SOFTMAX_ROWS: return sr_softmax_rows(op.u.ew.y, op.u.ew.rows, op.u.ew.cols, op.u.ew.dtype, stream);
+    case SR_OP_ADD_SCALED: return sr_add_scaled(op.u.add.a, op.u.add.b, op.u.add.y, op.u.add.n, op.u.add.s, op.u.add.dtype, stream);
     case SR_OP_GATHER_ROWS: return sr_gather_rows(op.u.gather.x, op.u.gather.sel, op.u.gather.y, op.u.gather.nsel, op.u.gather.row_bytes, stream);
     default: sr_set_error("sr_plan_run: unknown op kind %d", op.kind); return SR_ERR_INVALID;
   }

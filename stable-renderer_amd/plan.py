@@ -132,6 +132,13 @@ class PlanBuilder:
         a.x, a.y, a.n, a.dtype, a.rows, a.cols = O._p(x), O._p(x), x.numel(), O.DT[x.dtype], rows, cols
         self._emit(L.OP_SOFTMAX_ROWS, "ew", a)
 
+    def add(self, a, b, y, s=1.0):
+        """y = a + s*b (same shape / dtype)"""
+        self.hold(a, b, y)
+        ar = L._Add()
+        ar.a, ar.b, ar.y, ar.n, ar.s, ar.dtype = O._p(a), O._p(b), O._p(y), a.numel(), s, O.DT[a.dtype]
+        self._emit(L.OP_ADD_SCALED, "add", ar)
+
     def gather_rows(self, x, sel, y, nsel, row_bytes):
         self.hold(x, sel, y)
         a = L._Gather()

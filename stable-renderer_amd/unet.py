@@ -27,38 +27,150 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
+def pack_weights(sd, dtype, device, pad_cin=(), pad_cout=()):
+    """checkpoint tensors -> packed device tensors.  pad_cin: layer names whose input channels are zero-padded to the
+    K-step (conv_in); pad_cout: layers whose OUTPUT channels are padded too (ControlNet hint encoder, 16/32/96 channels),
+    so that the next layer sees a K-step-aligned channel count filled with exact zeros."""
+    ke = O.kelems(dtype)
+    w = {}
+    for k, v in sd.items():
+        if not k.endswith(".weight"):
+            continue
+        base = k[:-7]
+        b = sd.get(base + ".bias")
+        if v.dim() >= 2:
+            geglu = base.endswith("ff.net.0.proj")
+            cin_pad = _cdiv(v.shape[1], ke) * ke if (base in pad_cin or base in pad_cout) else None
+            if base in pad_cout and v.shape[0] % ke:
+                npad = _cdiv(v.shape[0], ke) * ke
+                v = torch.cat([v, v.new_zeros((npad - v.shape[0],) + tuple(v.shape[1:]))], 0)
+                if b is not None:
+                    b = torch.cat([b, b.new_zeros(npad - b.shape[0])], 0)
+            w[base] = O.pack_conv_weight(v, dtype, cin_pad=cin_pad, geglu=geglu).to(device)
+            if b is not None:
+                w[base + ".b"] = O.pack_bias(b, geglu=geglu).to(device)
+        else:                                                   # norm scale/shift stay fp32
+            w[base + ".g"] = v.float().contiguous().to(device)
+            w[base + ".beta"] = b.float().contiguous().to(device)
+    shapes = {k[:-7]: tuple(v.shape) for k, v in sd.items() if k.endswith(".weight")}
+    return w, shapes
+
+
+class BlockLowering:
+    """ResBlock / SpatialTransformer / BasicTransformerBlock -> plan ops; shared by the UNet and the ControlNet encoder."""
+
+    def __init__(self, pb, pro, W, shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx=None, sel=None):
+        self.pb, self.pro, self.W, self.shapes, self.B, self.cfg = pb, pro, W, shapes, B, cfg
+        self.emb_s, self.ctx, self.n_ctx, self.inject_idx, self.sel = emb_s, ctx, n_ctx, inject_idx, sel
+        self.ldt_ctx = _cdiv(n_ctx, 8) * 8
+
+    def resblock(self, p, x1, C1, x2, C2, Cout, HW, hh, ww):
+        pb, pro, W, B, cfg = self.pb, self.pro, self.W, self.B, self.cfg
+        mc, heads, emb_s, ctx, n_ctx, ldt_ctx = cfg["model_channels"], cfg["num_heads"], self.emb_s, self.ctx, self.n_ctx, self.ldt_ctx
+        inject_idx, sel = self.inject_idx, self.sel
+        cin = C1 + C2
+        er = pb.buf(B, Cout, dtype=torch.float32)
+        pb.igemm(emb_s, W[p + ".emb_layers.1"], er, B, 1, 1, 4 * mc, Cout, bias=W[p + ".emb_layers.1.b"], out_f32=1)
+        n1 = pb.buf(B, HW, cin)
+        pb.groupnorm(x1, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.beta"], n1, B, HW, C1, x2=x2, C2=C2, eps=1e-5, silu=True)
+        hmid = pb.buf(B, HW, Cout)
+        pb.igemm(n1, W[p + ".in_layers.2"], hmid, B, hh, ww, cin, Cout, KH=3, bias=W[p + ".in_layers.2.b"], rowvec=er)
+        n2 = pb.buf(B, HW, Cout)
+        pb.groupnorm(hmid, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.beta"], n2, B, HW, Cout, eps=1e-5, silu=True)
+        if (p + ".skip_connection") in W:
+            skip = pb.buf(B, HW, Cout)
+            pb.igemm(x1, W[p + ".skip_connection"], skip, B, hh, ww, C1, Cout, a2=x2, C2=C2, bias=W[p + ".skip_connection.b"])
+        else:
+            assert x2 is None and C1 == Cout
+            skip = x1
+        out = pb.buf(B, HW, Cout)
+        pb.igemm(n2, W[p + ".out_layers.3"], out, B, hh, ww, Cout, Cout, KH=3, bias=W[p + ".out_layers.3.b"], residual=skip)
+        return out
+
+    def tblock(self, p, hcur, Cc, HW):
+        pb, pro, W, B, cfg = self.pb, self.pro, self.W, self.B, self.cfg
+        mc, heads, emb_s, ctx, n_ctx, ldt_ctx = cfg["model_channels"], cfg["num_heads"], self.emb_s, self.ctx, self.n_ctx, self.ldt_ctx
+        inject_idx, sel = self.inject_idx, self.sel
+        d = Cc // heads
+        ln = pb.buf(B, HW, Cc)
+        pb.layernorm(hcur, W[p + ".norm1.g"], W[p + ".norm1.beta"], ln, B * HW, Cc)
+        q = pb.buf(B, HW, Cc)
+        pb.igemm(ln, W[p + ".attn1.to_q"], q, B * HW, 1, 1, Cc, Cc)
+        if inject_idx is None:
+            Bk, Tk, ldt = B, HW, _cdiv(HW, 8) * 8     # V^T rows padded to 16 B (pad columns stay zero)
+            k = pb.buf(B, HW, Cc)
+            vt = pb.buf(B, Cc, ldt, zero=True)
+            pb.igemm(ln, W[p + ".attn1.to_k"], k, B * HW, 1, 1, Cc, Cc)
+            pb.igemm(ln, W[p + ".attn1.to_v"], vt, B, HW, 1, Cc, Cc, transpose_out=1, ldt=ldt)
+        else:
+            nr = len(inject_idx)
+            Bk, Tk, ldt = 1, nr * HW, _cdiv(nr * HW, 8) * 8
+            k = pb.buf(1, Tk, Cc)
+            vt = pb.buf(1, Cc, ldt, zero=True)
+            # K/V of the injected frame(s) only (B-fold fewer projection FLOPs); the frame is picked on the device
+            src = pb.buf(nr, HW, Cc)
+            pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size())
+            pb.igemm(src, W[p + ".attn1.to_k"], k, Tk, 1, 1, Cc, Cc)
+            pb.igemm(src, W[p + ".attn1.to_v"], vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt)
+        a = pb.buf(B, HW, Cc)
+        pb.attention(q, k, vt, a, B, Bk, HW, Tk, heads, d, ldt)
+        h1 = pb.buf(B, HW, Cc)
+        pb.igemm(a, W[p + ".attn1.to_out.0"], h1, B * HW, 1, 1, Cc, Cc, bias=W[p + ".attn1.to_out.0.b"], residual=hcur)
+        # cross attention: K/V from the prompt, projected once in the prologue plan
+        ln2 = pb.buf(B, HW, Cc)
+        pb.layernorm(h1, W[p + ".norm2.g"], W[p + ".norm2.beta"], ln2, B * HW, Cc)
+        q2 = pb.buf(B, HW, Cc)
+        pb.igemm(ln2, W[p + ".attn2.to_q"], q2, B * HW, 1, 1, Cc, Cc)
+        k2 = pro.buf(B, n_ctx, Cc)
+        vt2 = pro.buf(B, Cc, ldt_ctx, zero=True)
+        cd = cfg["context_dim"]
+        pro.igemm(ctx, W[p + ".attn2.to_k"], k2, B * n_ctx, 1, 1, cd, Cc)
+        pro.igemm(ctx, W[p + ".attn2.to_v"], vt2, B, n_ctx, 1, cd, Cc, transpose_out=1, ldt=ldt_ctx)
+        a2 = pb.buf(B, HW, Cc)
+        pb.attention(q2, k2, vt2, a2, B, B, HW, n_ctx, heads, d, ldt_ctx)
+        h2 = pb.buf(B, HW, Cc)
+        pb.igemm(a2, W[p + ".attn2.to_out.0"], h2, B * HW, 1, 1, Cc, Cc, bias=W[p + ".attn2.to_out.0.b"], residual=h1)
+        ln3 = pb.buf(B, HW, Cc)
+        pb.layernorm(h2, W[p + ".norm3.g"], W[p + ".norm3.beta"], ln3, B * HW, Cc)
+        inner = self.shapes[p + ".ff.net.0.proj"][0] // 2
+        ff = pb.buf(B, HW, inner)
+        pb.igemm(ln3, W[p + ".ff.net.0.proj"], ff, B * HW, 1, 1, Cc, 2 * inner, bias=W[p + ".ff.net.0.proj.b"], act=2)
+        h3 = pb.buf(B, HW, Cc)
+        pb.igemm(ff, W[p + ".ff.net.2"], h3, B * HW, 1, 1, inner, Cc, bias=W[p + ".ff.net.2.b"], residual=h2)
+        return h3
+
+    def stransformer(self, p, x, Cc, HW, hh, ww, depth):
+        pb, pro, W, B, cfg = self.pb, self.pro, self.W, self.B, self.cfg
+        mc, heads, emb_s, ctx, n_ctx, ldt_ctx = cfg["model_channels"], cfg["num_heads"], self.emb_s, self.ctx, self.n_ctx, self.ldt_ctx
+        inject_idx, sel = self.inject_idx, self.sel
+        n = pb.buf(B, HW, Cc)
+        pb.groupnorm(x, W[p + ".norm.g"], W[p + ".norm.beta"], n, B, HW, Cc, eps=1e-6, silu=False)
+        hcur = pb.buf(B, HW, Cc)
+        pb.igemm(n, W[p + ".proj_in"], hcur, B, hh, ww, Cc, Cc, bias=W[p + ".proj_in.b"])
+        for i in range(depth):
+            hcur = self.tblock(f"{p}.transformer_blocks.{i}", hcur, Cc, HW)
+        out = pb.buf(B, HW, Cc)
+        pb.igemm(hcur, W[p + ".proj_out"], out, B, hh, ww, Cc, Cc, bias=W[p + ".proj_out.b"], residual=x)
+        return out
+
+
+
 class UNet:
     def __init__(self, state_dict, cfg=None, dtype=torch.float16, device="cuda"):
         self.cfg = dict(SD15_CFG if cfg is None else cfg)
         self.dtype, self.device = dtype, torch.device(device)
         self.ke = O.kelems(dtype)
-        self.w = {}
-        sd = state_dict
-        for k, v in sd.items():
-            if not k.endswith(".weight"):
-                continue
-            base = k[:-7]
-            b = sd.get(base + ".bias")
-            if v.dim() >= 2:
-                geglu = base.endswith("ff.net.0.proj")
-                cin_pad = None
-                if base == "input_blocks.0.0":
-                    cin_pad = _cdiv(v.shape[1], self.ke) * self.ke
-                self.w[base] = O.pack_conv_weight(v, dtype, cin_pad=cin_pad, geglu=geglu).to(self.device)
-                if b is not None:
-                    self.w[base + ".b"] = O.pack_bias(b, geglu=geglu).to(self.device)
-            else:                                                   # norm scale/shift stay fp32
-                self.w[base + ".g"] = v.float().contiguous().to(self.device)
-                self.w[base + ".beta"] = b.float().contiguous().to(self.device)
-        self.shapes = {k[:-7]: tuple(v.shape) for k, v in sd.items() if k.endswith(".weight")}
+        self.w, self.shapes = pack_weights(state_dict, dtype, self.device, pad_cin=("input_blocks.0.0",))
 
     # ------------------------------------------------------------------------------------------------
-    def build(self, B, h, w, inject_idx=None, n_ctx=77):
+    def build(self, B, h, w, inject_idx=None, n_ctx=77, control=None):
         """-> dict(prologue=Plan, step=Plan, x=(B,4,h,w) fp32 input buffer, t=(B,) fp32, ctx=(B,n_ctx,ctx_dim),
         out=(B,4,h,w) fp32, inject=(n_rand,) int32 device tensor or None).  inject_idx: list of batch indices whose
         post-LayerNorm tokens every batch entry attends to in self-attention (OverlapCorresponder.pre_atten_inject) or
         None.  The indices live in a device tensor read at run time, so the plan (and its captured graph) is reused when
-        the random frame changes between sampling runs: only ``inject`` is rewritten."""
+        the random frame changes between sampling runs: only ``inject`` is rewritten.
+        control: optional dict(output=[12 NHWC tensors], middle=NHWC tensor) produced by ControlNet.build for the same
+        (B,h,w): added to the skips / middle output as apply_control does (openaimodel.py:374-386, :899, :907)."""
         cfg, dt, dev = self.cfg, self.dtype, self.device
         pb = PlanBuilder(dev, dt)
         pro = PlanBuilder(dev, dt)                     # prompt-only work (cross-attention K/V)
@@ -83,85 +195,8 @@ class UNet:
         emb_s = pb.buf(B, 4 * mc)
         pb.silu(e2, emb_s)                             # every ResBlock applies SiLU first (emb_layers.0)
 
-        def resblock(p, x1, C1, x2, C2, Cout, HW, hh, ww):
-            cin = C1 + C2
-            er = pb.buf(B, Cout, dtype=torch.float32)
-            pb.igemm(emb_s, W[p + ".emb_layers.1"], er, B, 1, 1, 4 * mc, Cout, bias=W[p + ".emb_layers.1.b"], out_f32=1)
-            n1 = pb.buf(B, HW, cin)
-            pb.groupnorm(x1, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.beta"], n1, B, HW, C1, x2=x2, C2=C2, eps=1e-5, silu=True)
-            hmid = pb.buf(B, HW, Cout)
-            pb.igemm(n1, W[p + ".in_layers.2"], hmid, B, hh, ww, cin, Cout, KH=3, bias=W[p + ".in_layers.2.b"], rowvec=er)
-            n2 = pb.buf(B, HW, Cout)
-            pb.groupnorm(hmid, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.beta"], n2, B, HW, Cout, eps=1e-5, silu=True)
-            if (p + ".skip_connection") in W:
-                skip = pb.buf(B, HW, Cout)
-                pb.igemm(x1, W[p + ".skip_connection"], skip, B, hh, ww, C1, Cout, a2=x2, C2=C2, bias=W[p + ".skip_connection.b"])
-            else:
-                assert x2 is None and C1 == Cout
-                skip = x1
-            out = pb.buf(B, HW, Cout)
-            pb.igemm(n2, W[p + ".out_layers.3"], out, B, hh, ww, Cout, Cout, KH=3, bias=W[p + ".out_layers.3.b"], residual=skip)
-            return out
-
-        def tblock(p, hcur, Cc, HW):
-            d = Cc // heads
-            ln = pb.buf(B, HW, Cc)
-            pb.layernorm(hcur, W[p + ".norm1.g"], W[p + ".norm1.beta"], ln, B * HW, Cc)
-            q = pb.buf(B, HW, Cc)
-            pb.igemm(ln, W[p + ".attn1.to_q"], q, B * HW, 1, 1, Cc, Cc)
-            if inject_idx is None:
-                Bk, Tk, ldt = B, HW, _cdiv(HW, 8) * 8     # V^T rows padded to 16 B (pad columns stay zero)
-                k = pb.buf(B, HW, Cc)
-                vt = pb.buf(B, Cc, ldt, zero=True)
-                pb.igemm(ln, W[p + ".attn1.to_k"], k, B * HW, 1, 1, Cc, Cc)
-                pb.igemm(ln, W[p + ".attn1.to_v"], vt, B, HW, 1, Cc, Cc, transpose_out=1, ldt=ldt)
-            else:
-                nr = len(inject_idx)
-                Bk, Tk, ldt = 1, nr * HW, _cdiv(nr * HW, 8) * 8
-                k = pb.buf(1, Tk, Cc)
-                vt = pb.buf(1, Cc, ldt, zero=True)
-                # K/V of the injected frame(s) only (B-fold fewer projection FLOPs); the frame is picked on the device
-                src = pb.buf(nr, HW, Cc)
-                pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size())
-                pb.igemm(src, W[p + ".attn1.to_k"], k, Tk, 1, 1, Cc, Cc)
-                pb.igemm(src, W[p + ".attn1.to_v"], vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt)
-            a = pb.buf(B, HW, Cc)
-            pb.attention(q, k, vt, a, B, Bk, HW, Tk, heads, d, ldt)
-            h1 = pb.buf(B, HW, Cc)
-            pb.igemm(a, W[p + ".attn1.to_out.0"], h1, B * HW, 1, 1, Cc, Cc, bias=W[p + ".attn1.to_out.0.b"], residual=hcur)
-            # cross attention: K/V from the prompt, projected once in the prologue plan
-            ln2 = pb.buf(B, HW, Cc)
-            pb.layernorm(h1, W[p + ".norm2.g"], W[p + ".norm2.beta"], ln2, B * HW, Cc)
-            q2 = pb.buf(B, HW, Cc)
-            pb.igemm(ln2, W[p + ".attn2.to_q"], q2, B * HW, 1, 1, Cc, Cc)
-            k2 = pro.buf(B, n_ctx, Cc)
-            vt2 = pro.buf(B, Cc, ldt_ctx, zero=True)
-            cd = cfg["context_dim"]
-            pro.igemm(ctx, W[p + ".attn2.to_k"], k2, B * n_ctx, 1, 1, cd, Cc)
-            pro.igemm(ctx, W[p + ".attn2.to_v"], vt2, B, n_ctx, 1, cd, Cc, transpose_out=1, ldt=ldt_ctx)
-            a2 = pb.buf(B, HW, Cc)
-            pb.attention(q2, k2, vt2, a2, B, B, HW, n_ctx, heads, d, ldt_ctx)
-            h2 = pb.buf(B, HW, Cc)
-            pb.igemm(a2, W[p + ".attn2.to_out.0"], h2, B * HW, 1, 1, Cc, Cc, bias=W[p + ".attn2.to_out.0.b"], residual=h1)
-            ln3 = pb.buf(B, HW, Cc)
-            pb.layernorm(h2, W[p + ".norm3.g"], W[p + ".norm3.beta"], ln3, B * HW, Cc)
-            inner = self.shapes[p + ".ff.net.0.proj"][0] // 2
-            ff = pb.buf(B, HW, inner)
-            pb.igemm(ln3, W[p + ".ff.net.0.proj"], ff, B * HW, 1, 1, Cc, 2 * inner, bias=W[p + ".ff.net.0.proj.b"], act=2)
-            h3 = pb.buf(B, HW, Cc)
-            pb.igemm(ff, W[p + ".ff.net.2"], h3, B * HW, 1, 1, inner, Cc, bias=W[p + ".ff.net.2.b"], residual=h2)
-            return h3
-
-        def stransformer(p, x, Cc, HW, hh, ww, depth):
-            n = pb.buf(B, HW, Cc)
-            pb.groupnorm(x, W[p + ".norm.g"], W[p + ".norm.beta"], n, B, HW, Cc, eps=1e-6, silu=False)
-            hcur = pb.buf(B, HW, Cc)
-            pb.igemm(n, W[p + ".proj_in"], hcur, B, hh, ww, Cc, Cc, bias=W[p + ".proj_in.b"])
-            for i in range(depth):
-                hcur = tblock(f"{p}.transformer_blocks.{i}", hcur, Cc, HW)
-            out = pb.buf(B, HW, Cc)
-            pb.igemm(hcur, W[p + ".proj_out"], out, B, hh, ww, Cc, Cc, bias=W[p + ".proj_out.b"], residual=x)
-            return out
+        low = BlockLowering(pb, pro, W, self.shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx, sel)
+        resblock, stransformer = low.resblock, low.stransformer
 
         # ---- encoder ---------------------------------------------------------------------------------
         cin_pad = _cdiv(cfg["in_channels"], self.ke) * self.ke
@@ -195,6 +230,14 @@ class UNet:
         cur = resblock("middle_block.0", cur, ch, None, 0, ch, hh * ww, hh, ww)
         cur = stransformer("middle_block.1", cur, ch, hh * ww, hh, ww, cfg["transformer_depth_middle"])
         cur = resblock("middle_block.2", cur, ch, None, 0, ch, hh * ww, hh, ww)
+
+        def add_control(x, c):
+            y = pb.buf(*x.shape)
+            pb.add(x, c, y)
+            return y
+        ctrl_out = list(control["output"]) if control is not None else None
+        if control is not None and control.get("middle") is not None:
+            cur = add_control(cur, control["middle"])
         # ---- decoder ---------------------------------------------------------------------------------
         tdo = list(cfg["transformer_depth_output"])
         bo = 0
@@ -203,6 +246,10 @@ class UNet:
             for i in range(cfg["num_res_blocks"][lev] + 1):
                 skip, cs, sh, sw = hs.pop()
                 assert (sh, sw) == (hh, ww)
+                if ctrl_out:
+                    c_ = ctrl_out.pop()
+                    if c_ is not None:
+                        skip = add_control(skip, c_)
                 cur = resblock(f"output_blocks.{bo}.0", cur, ch, skip, cs, cout, hh * ww, hh, ww)
                 ch = cout
                 depth = tdo.pop()                      # the reference pops from the END (openaimodel.py:737)

@@ -90,3 +90,27 @@ def test_corrmap_errors():
     assert int(cm.writtens.sum()) == 0
     with pytest.raises(ValueError):
         cm.update(torch.rand(4, 4, 3).cuda(), ids[0])      # 3-D id map: hangs forever in the reference
+
+
+def test_corrmap_dump_load_interchange(tmp_path):
+    """on-disk format of CorrespondMap (corrmap.py:738-872): load a directory dumped BY THE REFERENCE, and dump one the
+    reference's Load would read identically (PNG bytes decode to the same arrays)."""
+    from PIL import Image
+    from stable_renderer_amd.corrmap import CorrespondMap
+    d = np.load(os.path.join(GOLD, "corrmap_dump_io.npz"))
+    m = CorrespondMap.Load(os.path.join(GOLD, "corrmap_dump", "gold"))
+    assert (m.k, m.height, m.width) == (2, 8, 8)
+    assert np.array_equal(m._values.cpu().numpy(), d["values_back"])            # what the reference's Load returns
+    assert np.array_equal(m.writtens.cpu().numpy(), d["writtens_back"])
+    m2 = CorrespondMap(k=2, height=8, width=8, name="gold")
+    m2._values.copy_(T(d["values_in"]))
+    m2._writtens.copy_(T(d["writtens_in"]).to(torch.uint8))
+    p = m2.dump(str(tmp_path))
+    for i in range(4):
+        for fn in (f"{i}.png", f"{i}_written.png"):
+            a = np.array(Image.open(os.path.join(p, fn)))
+            b = np.array(Image.open(os.path.join(GOLD, "corrmap_dump", "gold", fn)))
+            assert np.array_equal(a, b), fn
+    z = m2.dump(str(tmp_path), name="z", zip=True)
+    m3 = CorrespondMap.Load(z)
+    assert np.array_equal(m3._values.cpu().numpy(), d["values_back"])

@@ -91,3 +91,34 @@ def test_vae_decoder(dtype, atol):
     img = p2["img"].cpu()
     assert (img - T(d["img"])).abs().max().item() < atol
     assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
+def test_controlnet_into_unet(dtype, atol):
+    """ControlNet encoder plan -> residuals added inside the UNet plan, vs the reference's cldm.ControlNet + UNetModel"""
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    from stable_renderer_amd.controlnet import ControlNet
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    d = np.load(os.path.join(GOLD, "controlnet_tiny.npz"))
+    net = UNet(_sd("unet_tiny_keys.json", 1), cfg, dtype=dtype)
+    cn = ControlNet(_sd("controlnet_tiny_keys.json", 5), cfg, dtype=dtype, strength=0.8)
+    x, t, ctx, hint = T(d["x"]), T(d["t"]), T(d["ctx"]), T(d["hint"])
+    B = x.shape[0]
+    # the UNet plan owns x/t/ctx; the ControlNet plan reads the same buffers, so build the UNet inputs first
+    from stable_renderer_amd.plan import PlanBuilder
+    pb = PlanBuilder(net.device, dtype)
+    x_in = pb.buf(B, 4, 16, 16, dtype=torch.float32, zero=True)
+    t_in = pb.buf(B, dtype=torch.float32, zero=True)
+    ctx_in = pb.buf(B, 77, 64, zero=True)
+    cp = cn.build(B, 16, 16, x_in, t_in, ctx_in)
+    up = net.build(B, 16, 16, control=dict(output=cp["output"], middle=cp["middle"]))
+    x_in.copy_(x); t_in.copy_(t); ctx_in.copy_(ctx.to(dtype)); cp["hint"].copy_(hint)
+    up["x"].copy_(x); up["t"].copy_(t); up["ctx"].copy_(ctx.to(dtype))
+    cp["prologue"].run(); up["prologue"].run()
+    cp["step"].run(); up["step"].run()
+    torch.cuda.synchronize()
+    mid = cp["middle"].float().cpu().reshape(B, 2, 2, 256).permute(0, 3, 1, 2) / 0.8
+    assert (mid - T(d["mid"])).abs().max().item() < atol * max(1.0, float(T(d["mid"]).abs().max()))
+    y = up["out"].cpu()
+    ref = T(d["y"])
+    assert (y - ref).abs().max().item() < atol * max(1.0, ref.abs().max().item()), (y - ref).abs().max()

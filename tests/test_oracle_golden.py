@@ -186,3 +186,16 @@ def test_e2e_sampling(gold):
         ref = T(d[f"{name}_samples"])
         err = (s - ref).abs().max().item()
         assert err < 2e-3 * max(1.0, ref.abs().max().item()), (name, err)
+
+
+def test_controlnet(gold):
+    d = gold("controlnet_tiny")
+    sd_c = _sd_from_keys("controlnet_tiny_keys.json", 5)
+    sd_u = _sd_from_keys("unet_tiny_keys.json", 1)
+    with torch.no_grad():
+        c = O.controlnet_forward(sd_c, TINY, T(d["x"]), T(d["hint"]), T(d["t"]), T(d["ctx"]), strength=0.8)
+        assert torch.allclose(c["middle"][0] / 0.8, T(d["mid"]), atol=2e-4, rtol=1e-4)
+        assert torch.allclose(c["output"][0] / 0.8, T(d["out0"]), atol=2e-4, rtol=1e-4)
+        assert torch.allclose(c["output"][11] / 0.8, T(d["out11"]), atol=2e-4, rtol=1e-4)
+        y = O.unet_forward(sd_u, TINY, T(d["x"]), T(d["t"]), T(d["ctx"]), control=c)
+    assert torch.allclose(y, T(d["y"]), atol=3e-4, rtol=1e-4), (y - T(d["y"])).abs().max()
