@@ -203,6 +203,19 @@ int sr_corrmap_update(const float* frame, int32_t Cf, const int32_t* ids, const 
                       int32_t check_sprite, int32_t check_material, int32_t mode_first, void* values,
                       uint8_t* writtens, int32_t kk, int32_t V, int32_t* winner, int32_t* err_flag, void* stream);
 
+/* Legacy "latent overlapping" (legacy_codes/stable_rendering_algo/overlap/overlap.py:83-152 Overlap.__call__ and :180-222
+ * ResizeOverlap.__call__ with nearest interpolation; algorithms.py:34-118), fused at latent resolution:
+ * every output cell (f,i,j) looks up the corr-map pixel (f, i*H/h, j*W/w) that the nearest down-sampling would keep, walks
+ * that vertex's trace (CSR: offsets / tr_f / tr_y / tr_x in (frame,y,x) order), gathers the latent cells under the trace
+ * pixels ((2r+1)-pixel clamped DIAGONAL pooling, overlap.py:69-76), forms the weighted mean (algo 0 average, 1 frame
+ * distance, 2 pixel distance, 3 view normal incl. the reference's column-sum-per-row normalisation) and blends with alpha;
+ * keep_nonzero: ResizeOverlap's where(ovlp != 0, ovlp, orig).  Jacobi form: reads x, writes y (the reference updates in
+ * place in dict order, which only differs for radius > 0).  x,y: (T,C,h,w) fp32; pix_vert: (T*H*W) vertex index or -1. */
+int sr_legacy_overlap(const float* x, float* y, const int32_t* pix_vert, const int32_t* offsets, const int32_t* tr_f,
+                      const int32_t* tr_y, const int32_t* tr_x, const float* view_normal, int32_t T, int32_t C, int32_t h,
+                      int32_t w, int32_t H, int32_t W, float alpha, int32_t radius, int32_t algo, int32_t keep_nonzero,
+                      void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Software rasterizer for the G-buffer pass (engine/shaders/default_Gbuffer.{vert,frag}.glsl,
  * engine/managers/renderManager.py:499-571).  One call = one draw task (mesh x material). */

@@ -494,6 +494,52 @@ def sec_controlnet():
         save("controlnet_tiny", x=x, t=t, ctx=ctx, hint=hint, y=y, mid=outs[-1], out0=outs[0], out11=outs[11])
 
 
+def sec_legacy():
+    """legacy Overlap / ResizeOverlap with the four algorithms (legacy_codes/stable_rendering_algo/overlap/*)"""
+    sys.path.insert(0, os.path.join(R.REF, "legacy_codes"))
+    R.import_corrmap()            # seeds a bare ``engine.static`` package (the real __init__ pulls in OpenGL)
+    sys.modules["engine.static"].Color = type("Color", (), {})       # only imported by name, never used on this path
+    import importlib
+    ov = importlib.import_module("stable_rendering_algo.overlap.overlap")
+    alg = importlib.import_module("stable_rendering_algo.overlap.algorithms")
+    sch = importlib.import_module("stable_rendering_algo.overlap.overlap_scheduler")
+    dc = importlib.import_module("stable_rendering_algo.data_classes.correspondence_map")
+    g = torch.Generator().manual_seed(8)
+    T, H, W, C, h, w = 3, 16, 16, 4, 4, 4
+    ids = torch.zeros(T, H, W, 4, dtype=torch.int32)
+    ids[..., 0] = 1
+    ids[..., 2] = torch.randint(0, 12, (T, H, W), generator=g, dtype=torch.int32)   # >= 100 vertices: the reference
+    ids[..., 3] = torch.randint(0, 12, (T, H, W), generator=g, dtype=torch.int32)   # divides by len(corr_map)//100
+    ids[torch.rand(T, H, W, generator=g) < 0.3] = 0
+    cmap = {}
+    for f in range(T):
+        for i in range(H):
+            for j in range(W):
+                k = tuple(int(v) for v in ids[f, i, j])
+                if k == (0, 0, 0, 0):
+                    continue
+                cmap.setdefault(k, []).append(([i, j], f))
+    cm = dc.CorrespondenceMap(cmap, W, H, T)
+    frames = [rnd(20 + f, 1, C, H, W) for f in range(T)]
+    lat = [rnd(30 + f, 1, C, h, w) for f in range(T)]
+    vn = torch.rand(T, H, W, generator=g)
+    out = dict(ids=ids, frames=torch.stack(frames), latents=torch.stack(lat), view_normal=vn)
+    algos = dict(average=alg.AverageDistance(), frame=alg.FrameDistance(), pixel=alg.PixelDistance(), view_normal=alg.PerpendicularViewNormal())
+    for name, a in algos.items():
+        for radius in (0, 1):
+            o = ov.Overlap(alpha_scheduler=sch.Scheduler(interpolate_begin=0.6), kernel_radius_scheduler=sch.Scheduler(interpolate_begin=float(radius)),
+                           algorithm=a, verbose=False)
+            with quiet(), one_thread():
+                res = o([f.clone() for f in frames], cm, step=1, timestep=500, view_normal_map=vn.unsqueeze(-1))
+            out[f"full_{name}_r{radius}"] = res
+            ro = ov.ResizeOverlap(alpha_scheduler=sch.Scheduler(interpolate_begin=0.6), kernel_radius_scheduler=sch.Scheduler(interpolate_begin=float(radius)),
+                                  algorithm=a, verbose=False)
+            with quiet(), one_thread():
+                res2 = ro([l.clone() for l in lat], cm, step=1, timestep=500, view_normal_map=vn.unsqueeze(-1))
+            out[f"resize_{name}_r{radius}"] = torch.stack(res2)
+    save("legacy_overlap", **out)
+
+
 def sec_dump():
     """CorrespondMap.dump / Load round trip by the reference (corrmap.py:738-872): the dumped directory itself is the
     fixture (tests/golden/corrmap_dump/*), plus the tensors that went in and came back."""
@@ -514,7 +560,7 @@ def sec_dump():
 
 
 SECTIONS = dict(math=sec_math, idmap=sec_idmap, overlap=sec_overlap, corrmap=sec_corrmap, noisepool=sec_noisepool,
-                sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet)
+                sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet, legacy=sec_legacy)
 
 if __name__ == "__main__":
     todo = _ARGV or list(SECTIONS)

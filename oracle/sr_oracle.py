@@ -546,3 +546,77 @@ def controlnet_forward(sd, cfg, x, hint, t, ctx, strength=1.0):
     h = _resblock(sd, "middle_block.2", h, emb)
     mid = F.conv2d(h, sd["middle_block_out.0.weight"], sd["middle_block_out.0.bias"])
     return {"output": [o * strength for o in outs], "middle": [mid * strength]}
+
+
+# ------------------------------------------------------------------------------------------------------
+# Legacy overlap (legacy_codes/stable_rendering_algo/overlap/overlap.py:83-152,180-222; algorithms.py:34-118)
+def legacy_corr_map(ids: np.ndarray):
+    """(T,H,W,4) int ids -> dict {id_tuple: [((y,x), frame), ...]} in (frame,y,x) order; all-zero ids skipped
+    (data_classes/correspondence_map.py:150-166)."""
+    m = {}
+    T, H, W, _ = ids.shape
+    for f in range(T):
+        for i in range(H):
+            for j in range(W):
+                k = tuple(int(v) for v in ids[f, i, j])
+                if k == (0, 0, 0, 0):
+                    continue
+                m.setdefault(k, []).append(((i, j), f))
+    return m
+
+
+def _legacy_weights(algo, fs, ys, xs, vn):
+    fs, ys, xs = np.asarray(fs, np.float32), np.asarray(ys, np.float32), np.asarray(xs, np.float32)
+    n = len(fs)
+    if algo == "average":
+        return np.ones((n, n), np.float32)
+    if algo == "frame":
+        return (1.0 / (np.abs(fs[:, None] - fs[None, :]) + 1.0)).astype(np.float32)
+    if algo == "pixel":
+        return (1.0 / (np.abs(xs[:, None] - xs[None, :]) + np.abs(ys[:, None] - ys[None, :]) + 1.0)).astype(np.float32)
+    if algo == "view_normal":                                     # |1 - vn_j| broadcast over rows (algorithms.py:112-114)
+        d = np.abs(np.ones_like(vn)[:, None] - vn[None, :])
+        return (1.0 / (d + 1.0)).astype(np.float32)
+    raise ValueError(algo)
+
+
+def legacy_overlap(frames: np.ndarray, ids: np.ndarray, alpha, radius=0, algo="average", view_normal=None, sequential=True):
+    """frames (T,1,C,H,W) fp32 at corr-map resolution.  sequential=True reproduces the reference exactly: the 'copy' it
+    writes to shares storage with the source (``.detach()``, overlap.py:103), so later vertices see earlier updates
+    (only observable for radius > 0).  sequential=False is the order-independent form the HIP kernel computes."""
+    src = frames.astype(np.float32).copy()
+    out = src if sequential else src.copy()
+    T, _, C, H, W = src.shape
+    for key, info in legacy_corr_map(ids).items():
+        if len(info) == 1:
+            continue
+        pos, fs = zip(*info)
+        ys, xs = zip(*pos)
+        fs, ys, xs = list(fs), list(ys), list(xs)
+        lat = src[fs, 0][:, :, ys, xs] if False else np.stack([src[f, 0, :, y, x] for f, y, x in zip(fs, ys, xs)])   # (n,C)
+        pooled = np.zeros_like(lat)
+        for t, (f, y, x) in enumerate(zip(fs, ys, xs)):
+            acc = np.zeros(C, np.float32)
+            for k in range(-radius, radius + 1):                 # a diagonal of 2r+1 pixels, clamped (overlap.py:69-76)
+                acc += src[f, 0, :, min(max(y + k, 0), H - 1), min(max(x + k, 0), W - 1)]
+            pooled[t] = acc / np.float32(2 * radius + 1)
+        vn = None if view_normal is None else np.asarray([view_normal[f, y, x] for f, y, x in zip(fs, ys, xs)], np.float32)
+        w = _legacy_weights(algo, fs, ys, xs, vn)
+        ov = (w @ pooled) / w.sum(axis=0).reshape(-1, 1)          # column sums applied per ROW, as the reference does
+        new = np.float32(alpha) * ov + np.float32(1 - alpha) * lat
+        for t, (f, y, x) in enumerate(zip(fs, ys, xs)):
+            out[f, 0, :, y, x] = new[t]
+    return out
+
+
+def legacy_resize_overlap(latents: np.ndarray, ids: np.ndarray, alpha, radius=0, algo="average", view_normal=None, sequential=True):
+    """ResizeOverlap.__call__ with nearest interpolation: latents (T,1,C,h,w), ids (T,H,W,4)"""
+    if alpha == 0:
+        return latents
+    T, _, C, h, w = latents.shape
+    H, W = ids.shape[1:3]
+    t = torch.from_numpy(latents.astype(np.float32))
+    up = torch.stack([F.interpolate(t[i], size=(H, W), mode="nearest") for i in range(T)]).numpy()
+    ov = legacy_overlap(up, ids, alpha, radius, algo, view_normal, sequential)
+    dn = torch.stack([F.interpolate(torch.from_numpy(ov[i]), size=(h, w), mode="nearest") for i in range(T)]).numpy()
+    return np.where(dn != 0, dn, latents)

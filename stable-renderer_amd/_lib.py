@@ -114,6 +114,7 @@ SYMBOLS = {
     "sr_idmap_masks": (C.c_int, [vp, vp, i64, vp]),
     "sr_overlap_build": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sr_overlap_step": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "sr_legacy_overlap": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, vp]),
     "sr_adain": (C.c_int, [vp, i64, i64, i64, i32, vp, i32, i64, i64, i64, i32, vp, i32, i32, f32, vp, vp]),
     "sr_noise_pool": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "sr_corrmap_update": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),

@@ -197,9 +197,80 @@ __global__ void corrmap_pass2(const float* __restrict__ frame, int Cf, const int
   writtens[cell] = 1;
 }
 
+// legacy Overlap / ResizeOverlap fused at latent resolution: one thread per output cell
+__global__ void legacy_overlap_kernel(const float* __restrict__ x, float* __restrict__ y, const int* __restrict__ pix_vert,
+                                      const int* __restrict__ offsets, const int* __restrict__ tr_f, const int* __restrict__ tr_y,
+                                      const int* __restrict__ tr_x, const float* __restrict__ vn, int T, int C, int h, int w, int H, int W,
+                                      float alpha, int radius, int algo, int keep_nonzero) {
+  const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= (int64_t)T * h * w) return;
+  const int j = (int)(cell % w), i = (int)((cell / w) % h), f = (int)(cell / ((int64_t)w * h));
+  // F.interpolate(mode='nearest'): src = floor(dst * in/out) (float scale as torch: in/out computed in fp32)
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  const int py = min((int)floorf((float)i * sy), H - 1), px = min((int)floorf((float)j * sx), W - 1);
+  const int64_t lhw = (int64_t)h * w;
+  const float* xf = x + (int64_t)f * C * lhw;
+  float* yo = y + (int64_t)f * C * lhw + (int64_t)i * w + j;
+  const int v = pix_vert[((int64_t)f * H + py) * W + px];
+  const int b = v >= 0 ? offsets[v] : 0, e = v >= 0 ? offsets[v + 1] : 0;
+  if (v < 0 || e - b < 2) {                                   // no id / vertex seen once: unchanged
+    for (int c = 0; c < C; ++c) yo[c * lhw] = xf[c * lhw + (int64_t)i * w + j];
+    return;
+  }
+  // up-sampled latent value of full-res pixel (yy,xx) of frame ff: nearest up-sampling = cell (floor(yy*h/H), floor(xx*w/W))
+  const float uy = (float)h / (float)H, ux = (float)w / (float)W;
+  auto cell_of_px = [&](int yy, int xx) -> int64_t {
+    const int ci = min((int)floorf((float)yy * uy), h - 1), cj = min((int)floorf((float)xx * ux), w - 1);
+    return (int64_t)ci * w + cj;
+  };
+  // which trace entry is this pixel?  (the one with the same (f,py,px))
+  int me = b;
+  for (int t = b; t < e; ++t) if (tr_f[t] == f && tr_y[t] == py && tr_x[t] == px) { me = t; break; }
+  const float my_vn = (algo == 3) ? vn[((int64_t)f * H + py) * W + px] : 0.f;
+  float norm = 0.f;
+  float acc[8];
+  for (int c = 0; c < C && c < 8; ++c) acc[c] = 0.f;
+  const float inv_r = 1.0f / (float)(2 * radius + 1);
+  for (int t = b; t < e; ++t) {
+    const int tf = tr_f[t], ty = tr_y[t], tx = tr_x[t];
+    float wgt;
+    if (algo == 0) wgt = 1.0f;
+    else if (algo == 1) wgt = 1.0f / (fabsf((float)tf - (float)f) + 1.0f);
+    else if (algo == 2) wgt = 1.0f / (fabsf((float)tx - (float)px) + fabsf((float)ty - (float)py) + 1.0f);
+    else wgt = 1.0f / (fabsf(1.0f - vn[((int64_t)tf * H + ty) * W + tx]) + 1.0f);
+    norm += (algo == 3) ? 0.f : wgt;
+    const float* xt = x + (int64_t)tf * C * lhw;
+    for (int c = 0; c < C && c < 8; ++c) {
+      float pooled = 0.f;
+      for (int k = -radius; k <= radius; ++k)
+        pooled += xt[c * lhw + cell_of_px(min(max(ty + k, 0), H - 1), min(max(tx + k, 0), W - 1))];
+      acc[c] += wgt * (pooled * inv_r);
+    }
+  }
+  if (algo == 3) norm = (float)(e - b) * (1.0f / (fabsf(1.0f - my_vn) + 1.0f));   // column sum of w[.,me] applied to row me
+  (void)me;
+  for (int c = 0; c < C && c < 8; ++c) {
+    const float orig = xf[c * lhw + (int64_t)i * w + j];
+    const float val = alpha * (acc[c] / norm) + (1.0f - alpha) * orig;
+    yo[c * lhw] = (keep_nonzero && val == 0.0f) ? orig : val;
+  }
+}
+
 inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
+
+extern "C" int sr_legacy_overlap(const float* x, float* y, const int32_t* pix_vert, const int32_t* offsets, const int32_t* tr_f,
+                                 const int32_t* tr_y, const int32_t* tr_x, const float* view_normal, int32_t T, int32_t C, int32_t h,
+                                 int32_t w, int32_t H, int32_t W, float alpha, int32_t radius, int32_t algo, int32_t keep_nonzero,
+                                 void* stream) {
+  if (!x || !y || !pix_vert || !offsets || !tr_f || !tr_y || !tr_x) SR_FAIL(SR_ERR_INVALID, "sr_legacy_overlap: null");
+  if (C > 8 || radius < 0 || algo < 0 || algo > 3 || (algo == 3 && !view_normal)) SR_FAIL(SR_ERR_INVALID, "sr_legacy_overlap: bad args");
+  hipLaunchKernelGGL(legacy_overlap_kernel, g1((int64_t)T * h * w), dim3(256), 0, sr_stream(stream), x, y, pix_vert, offsets, tr_f, tr_y, tr_x,
+                     view_normal, T, C, h, w, H, W, alpha, radius, algo, keep_nonzero);
+  SR_CHECK_LAUNCH("sr_legacy_overlap");
+  return SR_OK;
+}
 
 extern "C" int sr_idmap_masks(const int32_t* ids, float* masks, int64_t n, void* stream) {
   if (!ids || !masks) SR_FAIL(SR_ERR_INVALID, "sr_idmap_masks: null");

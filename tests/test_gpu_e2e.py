@@ -114,3 +114,33 @@ def test_corrmap_dump_load_interchange(tmp_path):
     z = m2.dump(str(tmp_path), name="z", zip=True)
     m3 = CorrespondMap.Load(z)
     assert np.array_equal(m3._values.cpu().numpy(), d["values_back"])
+
+
+def test_legacy_overlap_vs_reference():
+    """legacy Overlap / ResizeOverlap: radius 0 against the REFERENCE's outputs for all four algorithms; radius 1 against
+    the oracle's order-independent (Jacobi) form (the reference's in-place update order is not parallelisable)."""
+    import sr_oracle as ORC
+    from stable_renderer_amd import legacy_overlap as LO
+    d = np.load(os.path.join(GOLD, "legacy_overlap.npz"))
+    ids = T(d["ids"]).cuda()
+    cm = LO.CorrespondenceMap(ids)
+    ref_map = ORC.legacy_corr_map(d["ids"])
+    assert len(cm) == len(ref_map)
+    frames = [T(d["frames"][i]).cuda() for i in range(3)]
+    lat = [T(d["latents"][i]).cuda() for i in range(3)]
+    vn = T(d["view_normal"]).cuda()
+    algos = dict(average=LO.AverageDistance(), frame=LO.FrameDistance(), pixel=LO.PixelDistance(), view_normal=LO.PerpendicularViewNormal())
+    for name, a in algos.items():
+        for r in (0, 1):
+            kw = dict(alpha_scheduler=LO.Scheduler(interpolate_begin=0.6), kernel_radius_scheduler=LO.Scheduler(interpolate_begin=float(r)), algorithm=a)
+            full = LO.Overlap(**kw)(frames, cm, step=1, timestep=500, view_normal_map=vn).cpu().numpy()
+            rs = torch.stack(LO.ResizeOverlap(**kw)(lat, cm, step=1, timestep=500, view_normal_map=vn)).cpu().numpy()
+            if r == 0:
+                assert np.allclose(full, d[f"full_{name}_r0"], atol=2e-5, rtol=1e-5), name
+                assert np.allclose(rs, d[f"resize_{name}_r0"], atol=2e-5, rtol=1e-5), name
+            else:
+                assert np.allclose(full, ORC.legacy_overlap(d["frames"], d["ids"], 0.6, 1, name, d["view_normal"], sequential=False), atol=2e-5), name
+                assert np.allclose(rs, ORC.legacy_resize_overlap(d["latents"], d["ids"], 0.6, 1, name, d["view_normal"], sequential=False), atol=2e-5), name
+    # alpha == 0 returns the input list untouched (overlap.py:203-204)
+    z = LO.ResizeOverlap(LO.Scheduler(interpolate_begin=0.0), LO.Scheduler(), LO.AverageDistance())
+    assert z(lat, cm, step=1, timestep=500) is lat

@@ -199,3 +199,16 @@ def test_controlnet(gold):
         assert torch.allclose(c["output"][11] / 0.8, T(d["out11"]), atol=2e-4, rtol=1e-4)
         y = O.unet_forward(sd_u, TINY, T(d["x"]), T(d["t"]), T(d["ctx"]), control=c)
     assert torch.allclose(y, T(d["y"]), atol=3e-4, rtol=1e-4), (y - T(d["y"])).abs().max()
+
+
+def test_legacy_overlap(gold):
+    d = gold("legacy_overlap")
+    ids, frames, lat, vn = d["ids"], d["frames"], d["latents"], d["view_normal"]
+    for algo in ("average", "frame", "pixel", "view_normal"):
+        for r in (0, 1):
+            o = O.legacy_overlap(frames, ids, 0.6, r, algo, vn, sequential=True)
+            assert np.allclose(o, d[f"full_{algo}_r{r}"], atol=2e-5, rtol=1e-5), (algo, r)
+            o2 = O.legacy_resize_overlap(lat, ids, 0.6, r, algo, vn, sequential=True)
+            assert np.allclose(o2, d[f"resize_{algo}_r{r}"], atol=2e-5, rtol=1e-5), (algo, r)
+        # radius 0 is order independent: the parallel (Jacobi) form is identical
+        assert np.allclose(O.legacy_overlap(frames, ids, 0.6, 0, algo, vn, sequential=False), d[f"full_{algo}_r0"], atol=2e-5)
