@@ -11,6 +11,24 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t):
+    """gloo has no device collectives for every op: stage CUDA tensors through the host (tests on one GPU); RCCL runs
+    them on the device directly."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def broadcast(t, src, group=None):
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if _staged(t):
+        c = t.cpu()
+        dist.broadcast(c, src=src, group=group)
+        t.copy_(c)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 class ViewShard:
     def __init__(self, n_views, group=None):
         self.group = group
@@ -26,8 +44,15 @@ class ViewShard:
         if self.world == 1:
             return x_local
         x_local = x_local.contiguous()
+        if _staged(x_local):
+            c = x_local.cpu()
+            parts = [torch.empty_like(c) for _ in range(self.world)]
+            dist.all_gather(parts, c, group=self.group)
+            return torch.cat(parts, 0).to(x_local.device)
         full = torch.empty((self.n_views,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
-        dist.all_gather_into_tensor(full, x_local, group=self.group) if x_local.is_cuda else \
+        if x_local.is_cuda:
+            dist.all_gather_into_tensor(full, x_local, group=self.group)
+        else:
             dist.all_gather(list(full.split(self.n_local)), x_local, group=self.group)
         return full
 
@@ -46,9 +71,19 @@ class ViewShard:
         if self.world == 1:
             return frames_local
         frames_local = frames_local.contiguous()
+        dev = frames_local.device
+        if _staged(frames_local):
+            frames_local = frames_local.cpu()
         out = [torch.empty_like(frames_local) for _ in range(self.world)] if self.rank == 0 else None
         dist.gather(frames_local, out, dst=0, group=self.group)
-        return torch.cat(out, 0) if self.rank == 0 else None
+        return torch.cat(out, 0).to(dev) if self.rank == 0 else None
+
+    def owner_of(self, global_batch_index):
+        """global batch entry of calc_cond_uncond_batch's [uncond views | cond views] order -> (owner rank, index in that
+        rank's local batch [uncond local | cond local])"""
+        g = int(global_batch_index)
+        cond, view = g >= self.n_views, g % self.n_views
+        return view // self.n_local, (self.n_local if cond else 0) + view % self.n_local
 
 
 def timed_max_over_ranks(seconds, device):

@@ -111,7 +111,12 @@ class DiffusionRunner:
     ``sample()`` is the body of custom_ksampler -> comfy.sample.sample -> KSampler.sample -> sampler loop with the
     model call replaced by the native plan; the latent stays resident in HBM for the whole run."""
 
-    def __init__(self, unet, N, h, w, cfg_scale, n_ctx=77, use_graph=True):
+    def __init__(self, unet, N, h, w, cfg_scale, n_ctx=77, use_graph=True, shard=None):
+        """shard: optional parallel.ViewShard — this process then holds ``shard.n_local`` of the ``shard.n_views`` views of ONE
+        overlapped group; N must equal shard.n_local."""
+        self.shard = shard
+        if shard is not None and shard.world > 1:
+            assert N == shard.n_local
         self.unet, self.N, self.h, self.w = unet, N, h, w
         self.cfg_scale = float(cfg_scale)
         self.copies = 1 if math.isclose(self.cfg_scale, 1.0) else 2     # samplers.py:335 (skip uncond at cfg 1)
@@ -129,12 +134,17 @@ class DiffusionRunner:
     def _ensure_plan(self, inject_idx):
         """the plan depends only on HOW MANY frames are injected; which ones is a device tensor rewritten per run"""
         key = None if inject_idx is None else len(inject_idx)
+        sharded = self.shard is not None and self.shard.world > 1
         if self._plan is None or self._inject != key:
-            self._plan = self.unet.build(self.N * self.copies, self.h, self.w, inject_idx=inject_idx, n_ctx=self.n_ctx)
+            self._plan = self.unet.build(self.N * self.copies, self.h, self.w, inject_idx=inject_idx, n_ctx=self.n_ctx,
+                                         inject_external=sharded and inject_idx is not None)
             self._inject = key
             self._captured = False
-        if inject_idx is not None:
+        if inject_idx is not None and not sharded:
+            if any(int(i) < 0 or int(i) >= self.N * self.copies for i in inject_idx):
+                raise IndexError(f"injected frame index out of range: {list(inject_idx)}")
             self._plan["inject"].copy_(torch.tensor([int(i) for i in inject_idx], dtype=torch.int32))
+        self._inject_global = inject_idx
         return self._plan
 
     def set_conditioning(self, positive, negative):
@@ -159,6 +169,20 @@ class DiffusionRunner:
         n = self.x.numel()
         O.eps_scale_input(self.x, p["x"], self.copies, sigma)
         p["t"].fill_(float(timestep_index))
+        if len(p["points"]) > 0:
+            # view-sharded group: the injected frame's post-LayerNorm tokens live on one rank; run the plan segment by
+            # segment and broadcast them over xGMI at each of the 16 cut points
+            from . import parallel as PAR
+            for si, seg in enumerate(p["segments"]):
+                seg.run()
+                if si < len(p["points"]):
+                    ln, src = p["points"][si]
+                    for j, g in enumerate(self._inject_global):
+                        owner, li = self.shard.owner_of(g)
+                        if owner == self.shard.rank:
+                            src[j].copy_(ln[li])
+                        PAR.broadcast(src[j], owner, self.shard.group)
+            return p["out"]
         if self.use_graph:
             if not self._captured:
                 torch.cuda.current_stream().synchronize()
@@ -193,8 +217,14 @@ class DiffusionRunner:
         O.axpby(self.x, latent.to(dev, torch.float32).contiguous(), 1.0, s0)        # x = noise*s0 + latent
         inject = None
         if inject_n_rand is not None and inject_n_rand >= 0:
-            B = self.N * self.copies
+            n_all = self.N if self.shard is None else self.shard.n_views
+            B = n_all * self.copies
             inject = torch.randint(1, B, (inject_n_rand,)).tolist()       # global RNG; B counts cond + uncond entries
+            if self.shard is not None and self.shard.world > 1:           # every rank must use rank 0's draw
+                from . import parallel as PAR
+                t_inj = torch.tensor(inject, dtype=torch.int64)
+                PAR.broadcast(t_inj, 0, self.shard.group)
+                inject = t_inj.tolist()
         p = self._ensure_plan(inject)
         self._load_ctx(p)
         if noise_fn is None:

@@ -59,10 +59,14 @@ def pack_weights(sd, dtype, device, pad_cin=(), pad_cout=()):
 class BlockLowering:
     """ResBlock / SpatialTransformer / BasicTransformerBlock -> plan ops; shared by the UNet and the ControlNet encoder."""
 
-    def __init__(self, pb, pro, W, shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx=None, sel=None):
+    def __init__(self, pb, pro, W, shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx=None, sel=None, external=False):
         self.pb, self.pro, self.W, self.shapes, self.B, self.cfg = pb, pro, W, shapes, B, cfg
         self.emb_s, self.ctx, self.n_ctx, self.inject_idx, self.sel = emb_s, ctx, n_ctx, inject_idx, sel
         self.ldt_ctx = _cdiv(n_ctx, 8) * 8
+        # external=True (view-sharded multi-GPU): the injected frame's tokens come from another rank.  The plan is CUT
+        # after each norm1; ``segments`` are the plans between cuts and ``points`` the (ln, src) buffer pairs the host
+        # fills (owner: src <- ln[local index]) and broadcasts before launching the next segment.
+        self.external, self.segments, self.points = external, [], []
 
     def resblock(self, p, x1, C1, x2, C2, Cout, HW, hh, ww):
         pb, pro, W, B, cfg = self.pb, self.pro, self.W, self.B, self.cfg
@@ -109,7 +113,11 @@ class BlockLowering:
             vt = pb.buf(1, Cc, ldt, zero=True)
             # K/V of the injected frame(s) only (B-fold fewer projection FLOPs); the frame is picked on the device
             src = pb.buf(nr, HW, Cc)
-            pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size())
+            if self.external:
+                self.segments.append(pb.take())
+                self.points.append((ln, src))
+            else:
+                pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size())
             pb.igemm(src, W[p + ".attn1.to_k"], k, Tk, 1, 1, Cc, Cc)
             pb.igemm(src, W[p + ".attn1.to_v"], vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt)
         a = pb.buf(B, HW, Cc)
@@ -163,7 +171,7 @@ class UNet:
         self.w, self.shapes = pack_weights(state_dict, dtype, self.device, pad_cin=("input_blocks.0.0",))
 
     # ------------------------------------------------------------------------------------------------
-    def build(self, B, h, w, inject_idx=None, n_ctx=77, control=None):
+    def build(self, B, h, w, inject_idx=None, n_ctx=77, control=None, inject_external=False):
         """-> dict(prologue=Plan, step=Plan, x=(B,4,h,w) fp32 input buffer, t=(B,) fp32, ctx=(B,n_ctx,ctx_dim),
         out=(B,4,h,w) fp32, inject=(n_rand,) int32 device tensor or None).  inject_idx: list of batch indices whose
         post-LayerNorm tokens every batch entry attends to in self-attention (OverlapCorresponder.pre_atten_inject) or
@@ -182,8 +190,10 @@ class UNet:
         ldt_ctx = _cdiv(n_ctx, 8) * 8
         sel = None
         if inject_idx is not None:
+            if not inject_external and any(int(i) < 0 or int(i) >= B for i in inject_idx):
+                raise IndexError(f"injected frame index out of range for batch {B}: {list(inject_idx)}")
             sel = pb.buf(len(inject_idx), dtype=torch.int32)
-            sel.copy_(torch.tensor([int(i) for i in inject_idx], dtype=torch.int32))
+            sel.copy_(torch.tensor([int(i) if 0 <= int(i) < B else 0 for i in inject_idx], dtype=torch.int32))
 
         # ---- time embedding ------------------------------------------------------------------------
         temb = pb.buf(B, mc)
@@ -195,7 +205,7 @@ class UNet:
         emb_s = pb.buf(B, 4 * mc)
         pb.silu(e2, emb_s)                             # every ResBlock applies SiLU first (emb_layers.0)
 
-        low = BlockLowering(pb, pro, W, self.shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx, sel)
+        low = BlockLowering(pb, pro, W, self.shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx, sel, external=inject_external)
         resblock, stransformer = low.resblock, low.stransformer
 
         # ---- encoder ---------------------------------------------------------------------------------
@@ -272,4 +282,6 @@ class UNet:
         out = pb.buf(B, oc, hh, ww, dtype=torch.float32)
         pb.nhwc_to_nchw(o_nhwc, out, B, oc, hh * ww, oc)
         flops = pb.flops
-        return dict(prologue=pro.take(), step=pb.take(), x=x_in, t=t_in, ctx=ctx, out=out, flops=flops, inject=sel)
+        step = pb.take()
+        return dict(prologue=pro.take(), step=step, x=x_in, t=t_in, ctx=ctx, out=out, flops=flops, inject=sel,
+                    segments=low.segments + [step], points=low.points)
