@@ -50,8 +50,15 @@ class BakeBallScene:
 
 class FramePipeline:
     def __init__(self, unet, vae, scene, n_views=8, steps=20, cfg=8.0, sampler="ddim", scheduler="normal",
-                 corresponder=None, use_graph=True, bg_seed=1):
+                 corresponder=None, use_graph=True, bg_seed=1, shard=None):
+        """shard: optional parallel.ViewShard over the ``n_views`` of ONE overlapped group (one process per GPU): this process
+        then rasterises / diffuses / decodes only its own views; id maps are all-gathered once per call, latents once per
+        overlap step, the injected frame's tokens are broadcast per transformer block and decoded frames go to rank 0 for
+        the ordered corr-map update.  Without it the pipeline is a self-contained replica."""
         self.unet, self.vae, self.scene = unet, vae, scene
+        self.shard = shard if (shard is not None and shard.world > 1) else None
+        self.N_all = n_views
+        n_views = n_views if self.shard is None else self.shard.n_local
         self.N, self.steps, self.cfg, self.sampler, self.scheduler = n_views, steps, cfg, sampler, scheduler
         dev = unet.device
         self.W, self.H = scene.W, scene.H
@@ -63,7 +70,7 @@ class FramePipeline:
         # ignore_obj_mat_id_when_update=True is the reference option that avoids _update's double-gather IndexError on
         # partially covered frames (corrmap.py:703/710; reproduced in corrmap.py of this package)
         self.baker = DefaultCorresponder(update_corrmap_mode="first", ignore_obj_mat_id_when_update=True)
-        self.runner = DiffusionRunner(unet, n_views, self.h, self.w, cfg, use_graph=use_graph)
+        self.runner = DiffusionRunner(unet, n_views, self.h, self.w, cfg, use_graph=use_graph, shard=self.shard)
         self.vplan = vae.build(n_views, self.h, self.w)
         g = torch.Generator().manual_seed(bg_seed)
         self.bg_noise = torch.randn(1, self.H, self.W, 4, generator=g).to(dev)                # RenderManager.GlobalBGNoise
@@ -79,16 +86,20 @@ class FramePipeline:
 
     def render_views(self):
         """N consecutive frames -> EngineData (the per-frame part of _save_frame_data)."""
+        first = self.frame0 + (0 if self.shard is None else self.shard.rank * self.N)
         for i in range(self.N):
-            self.gbuf.render(self.scene.tasks(self.frame0 + i), self.scene.camera)
+            self.gbuf.render(self.scene.tasks(first + i), self.scene.camera)
             self.ids[i].copy_(self.gbuf.id)
             self.colors[i].copy_(self.gbuf.color[..., :3])
             alpha = self.gbuf.color[..., 3].contiguous()
             self.masks[i].copy_(1.0 - alpha)
             _, nz = O.noise_pool(self.gbuf.noise.unsqueeze(0), alpha.unsqueeze(0), self.bg_noise)
             self.noise[i].copy_(nz[0])
-        self.frame0 += self.N
+        self.frame0 += self.N_all
         idm = IDMap(self.ids)
+        self._ids_all = None
+        if self.shard is not None:
+            self._ids_all = IDMap(self.shard.gather_latents(self.ids))        # every rank needs every view's ids
         return EngineData(frame_indices=list(range(self.N)), color_maps=self.colors, id_maps=idm, masks=self.masks,
                           noise_maps=LATENT(samples=torch.zeros_like(self.noise), noise=self.noise),
                           correspond_maps={(self.scene.sprite, self.scene.material): self.scene.corrmap})
@@ -101,8 +112,16 @@ class FramePipeline:
                 raise ValueError("OverlapCorresponder only works with ddim or ddpm sampler_name.")   # _nodes/samplers.py:163-164
             n_rand = corr.pre_attn_inject_num_random_frames
 
-            def cb(ctx):
-                corr.step_finished(ed, ctx)
+            if self.shard is None:
+                def cb(ctx):
+                    corr.step_finished(ed, ctx)
+            else:
+                idx_all = self._ids_all.overlap_index(self.h, self.w)
+
+                def cb(ctx):
+                    if ctx.timestep < corr.step_finished_stop_inject_timestep:
+                        return
+                    self.shard.overlap_step(ctx.noise, lambda full: idx_all.step(full, corr.step_finished_inject_ratio))
         samples, inj = self.runner.sample(ed.noise_maps["noise"], self.steps, self.sampler, self.scheduler,
                                           latent_image=ed.noise_maps["samples"], inject_n_rand=n_rand, step_callback=cb)
         if isinstance(corr, OverlapCorresponder) and inj is not None:
@@ -131,13 +150,19 @@ class FramePipeline:
         t = mark("sampling", t)
         images = self.decode(samples)
         t = mark("vae_decode", t)
-        self.baker.finished(ed, images)
+        if self.shard is None:
+            self.baker.finished(ed, images)
+        else:
+            frames = self.shard.gather_frames_to_rank0(images)                # 'first' priority = frame order
+            if self.shard.rank == 0:
+                ed_all = EngineData(frame_indices=list(range(self.N_all)), id_maps=self._ids_all, correspond_maps=ed.correspond_maps)
+                self.baker.finished(ed_all, frames)
         mark("corrmap_update", t)
         return images
 
 
 def build_sd15_pipeline(dtype=torch.float16, n_views=8, steps=20, cfg=8.0, W=512, H=512, seed=0, unet_cfg=None,
-                        use_graph=True, vae_ch=128, device="cuda"):
+                        use_graph=True, vae_ch=128, device="cuda", shard=None):
     """Random-init SD1.5-shaped UNet + VAE decoder (no checkpoints offline; synth.py) on the bake_ball scene."""
     from . import synth
     from .unet import UNet, SD15_CFG
@@ -149,7 +174,7 @@ def build_sd15_pipeline(dtype=torch.float16, n_views=8, steps=20, cfg=8.0, W=512
     vns, vnorms = vae_decoder_names_shapes(ch=vae_ch)
     vae = VAEDecoder(synth.synth_state_dict(vns, seed=seed + 2, norm_names=vnorms), dtype=dtype, device=device)
     scene = BakeBallScene(W, H, device=device)
-    pipe = FramePipeline(unet, vae, scene, n_views=n_views, steps=steps, cfg=cfg, use_graph=use_graph)
+    pipe = FramePipeline(unet, vae, scene, n_views=n_views, steps=steps, cfg=cfg, use_graph=use_graph, shard=shard)
     g = torch.Generator().manual_seed(seed + 11)
     cd = cfgu["context_dim"]
     pipe.set_prompt(torch.randn(1, 77, cd, generator=g), torch.randn(1, 77, cd, generator=g))
