@@ -210,7 +210,8 @@ class DiffusionRunner:
         latent = torch.zeros_like(noise) if latent_image is None else latent_image * LATENT_SCALE
         if sampler == "ddim":
             g = torch.manual_seed(seed + 1)
-            torch.randn(tuple(noise.shape), generator=g, device="cpu")
+            n_grp = noise.shape[0] if self.shard is None else self.shard.n_views     # the draw is over the WHOLE group
+            torch.randn((n_grp,) + tuple(noise.shape[1:]), generator=g, device="cpu")
         max_denoise = math.isclose(float(self.ms.sigma_max), float(sig[0]), rel_tol=1e-05) or float(sig[0]) > float(self.ms.sigma_max)
         s0 = float(torch.sqrt(1.0 + sig[0] ** 2.0)) if max_denoise else float(sig[0])
         self.x.copy_(noise.to(dev, torch.float32))
