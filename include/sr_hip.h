@@ -62,6 +62,12 @@ typedef struct {
   int32_t out_f32;        /* 1: store fp32 regardless of dtype                                         */
   int32_t dtype;          /* sr_dtype                                                                  */
   float scale;            /* multiplies the accumulator (1.0 normally)                                 */
+  int32_t rowvec_ld;      /* row stride of rowvec in floats (0 = N): lets every ResBlock read its slice of ONE
+                             batched time-embedding projection                                         */
+  void* workspace;        /* optional fp32 scratch for split-K (small-M convs of the 8x8 / 16x16 levels: too few
+                             output tiles to fill 256 CUs).  NULL = never split.  May be shared by all ops
+                             of a stream; contents are dead after the call.                            */
+  int64_t workspace_bytes;
 } sr_igemm_args;
 int sr_igemm(const sr_igemm_args* args, void* stream);
 

@@ -18,7 +18,7 @@
 
 namespace {
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
                                                                         const int NT, const int nwg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,8 +79,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
     wrow[i] = (const char*)p.w + ((int64_t)n * KT * KE) * (int64_t)sizeof(T) + lchunk * 16;
   }
 
-  int s_tap = 0, s_kk = 0;
-  set_tap(0);
+  // split-K: blockIdx.y owns the K-steps [kt0, kt1) and writes raw fp32 partials to the workspace
+  int kt0 = 0, kt1 = KT;
+  if constexpr (SPLIT) {
+    kt0 = (int)((int64_t)KT * blockIdx.y / gridDim.y);
+    kt1 = (int)((int64_t)KT * (blockIdx.y + 1) / gridDim.y);
+#pragma unroll
+    for (int i = 0; i < NIQ; ++i) wrow[i] += (int64_t)kt0 * 128;
+  }
+  int s_tap = kt0 / KPT, s_kk = kt0 - s_tap * KPT;
+  set_tap(s_tap);
   auto stage = [&](int buf) {                            // issue the async loads of the next K-step
     char* tP = smem + buf * STAGE_BYTES;
     char* tQ = tP + BM * 128;
@@ -136,10 +144,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
     }
   };
   if constexpr (STAGES == 2) {
+    const int nk = kt1 - kt0;
     stage(0);
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();                                   // (vmcnt(0)+barrier) tile kt landed; buffer kt+1 is free
-      if (kt + 1 < KT) stage((kt + 1) & 1);
+      if (kt + 1 < nk) stage((kt + 1) & 1);
       compute(kt & 1);
     }
   } else {
@@ -164,7 +173,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   // ---- epilogue
   const float scale = p.scale;
   const int N = p.N;
-  if constexpr (!TRANS) {
+  const int ldr = p.rowvec_ld ? p.rowvec_ld : N;
+  if constexpr (SPLIT) {
+    float* ws = (float*)p.workspace + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + pm0 + tm * 16 + c16;
+      if (m >= M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + qn0 + tn * 16 + 4 * g4;
+        if (n >= N) continue;                              // N % 4 == 0 on this path
+        *(f32x4*)(ws + (int64_t)m * N + n) = acc[tn][tm];
+      }
+    }
+    return;
+  } else if constexpr (!TRANS) {
     const int ldo = (p.act == 2) ? (N >> 1) : N;
     const bool o32 = p.out_f32 || sizeof(T) == 4;
     const int oes = o32 ? 4 : 2;                             // output element size
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
           float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
           if (n < N) {                                       // N % 4 == 0 on this path
             if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
-            if (p.rowvec) { const float4 rv = *(const float4*)(p.rowvec + (int64_t)b * N + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+            if (p.rowvec) { const float4 rv = *(const float4*)(p.rowvec + (int64_t)b * ldr + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
           }
           if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
           else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
@@ -257,7 +281,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
         float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
         const int nv = (N - n) < 4 ? (N - n) : 4;
         if (p.bias) { for (int r = 0; r < nv; ++r) v[r] += p.bias[n + r]; }
-        if (p.rowvec) { for (int r = 0; r < nv; ++r) v[r] += p.rowvec[(int64_t)b * N + n + r]; }
+        if (p.rowvec) { for (int r = 0; r < nv; ++r) v[r] += p.rowvec[(int64_t)b * ldr + n + r]; }
         if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
         else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
         else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
@@ -346,15 +370,81 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   return SR_OK;
 }
 
+// out = act(scale * sum_z ws[z] + bias + rowvec) + residual, 4 consecutive channels per thread, fixed z order
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const sr_igemm_args p, const int M, const int rpb, const int S) {
+  const int N = p.N, n4 = N >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) * 4;
+  const float* ws = (const float*)p.workspace + (int64_t)m * N + n;
+  f32x4 acc = *(const f32x4*)ws;
+  for (int z = 1; z < S; ++z) { const f32x4 t = *(const f32x4*)(ws + (int64_t)z * M * N); acc += t; }
+  float v[4] = {acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale};
+  if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+  if (p.rowvec) {
+    const int ldr = p.rowvec_ld ? p.rowvec_ld : N;
+    const float4 rv = *(const float4*)(p.rowvec + (int64_t)(m / rpb) * ldr + n);
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+  if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
+  else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
+  else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
+  const int64_t oi = (int64_t)m * N + n;
+  if (p.residual) {
+    if constexpr (sizeof(T) == 2) {
+      const h16x4 rr = *(const h16x4*)((const _Float16*)p.residual + oi);
+      v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
+    } else {
+      const float4 rr = *(const float4*)((const float*)p.residual + oi);
+      v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+    }
+  }
+  if (p.out_f32 || sizeof(T) == 4) *(float4*)((float*)p.out + oi) = make_float4(v[0], v[1], v[2], v[3]);
+  else { h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; *(h16x4*)((_Float16*)p.out + oi) = hv; }
+}
+
+template <typename T, int BM, int BN>
+int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int S, hipStream_t st) {
+  const int MT = (M + BM - 1) / BM, NTv = (a.N + BN - 1) / BN, nwg = MT * NTv;
+  constexpr int lds = 2 * (BM + BN) * 128;
+  auto k = igemm_kernel<T, BM, BN, 2, 2, 2, false, true>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  hipLaunchKernelGGL(k, dim3(nwg, S), dim3(256), lds, st, a, M, Ho, Wo, NTv, nwg);
+  const int64_t quads = (int64_t)M * (a.N >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a, M, Ho * Wo, S);
+  SR_CHECK_LAUNCH("sr_igemm(split-K)");
+  return SR_OK;
+}
+
 template <typename T, bool TRANS>
 int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int n128 = (a.N + 127) / 128, n64 = (a.N + 63) / 64;
   const int64_t wg_128x128 = (int64_t)((M + 127) / 128) * n128;
   const bool waste128 = (n128 * 128 - a.N) * 8 > a.N;          // >12.5% padded columns with BN=128
-  static const int force = getenv("SR_IGEMM_TILE") ? atoi(getenv("SR_IGEMM_TILE")) : 0;   // tuning aid: 1=256x128x3, 2=128x128, 3=128x64, 4=64x64
+  const char* fenv = getenv("SR_IGEMM_TILE"); const int force = fenv ? atoi(fenv) : 0;   // tuning aid: 1=256x128x3, 2=128x128, 3=128x64, 4=64x64
   if (force == 2) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 3) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 4) return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  // split-K: a long-K conv whose output has too few tiles for 256 CUs (8x8 / 16x16 UNet levels: 80 / 320 tiles of
+  // 128x128).  S splits of K run as grid.y, fp32 partials go through the caller's workspace and a fixed-order reduce
+  // kernel applies the epilogue (bit-reproducible; no float atomics).
+  if constexpr (!TRANS) {
+    const int KT = a.KH * a.KH * ((a.C1 + a.C2) / (int)(128 / sizeof(T)));
+    const char* senv = getenv("SR_SPLITK");                  // tuning aid: 0 = off, else the target workgroup count
+    const int target = senv ? atoi(senv) : 512;
+    if (force == 0 && target > 0 && a.workspace && a.act != 2 && a.N % 4 == 0 && KT >= 64) {
+      const int64_t tiles = waste128 ? (int64_t)((M + 127) / 128) * n64 : wg_128x128;
+      if (tiles * 2 <= target + target / 2) {
+        int S = (int)((target + tiles / 2) / tiles);
+        if (S > KT / 16) S = KT / 16;
+        const int64_t per = (int64_t)M * a.N * 4;
+        if ((int64_t)S * per > a.workspace_bytes) S = (int)(a.workspace_bytes / per);
+        if (S >= 2) return waste128 ? launch_split<T, 128, 64>(a, M, Ho, Wo, S, st) : launch_split<T, 128, 128>(a, M, Ho, Wo, S, st);
+      }
+    }
+  }
   const int64_t wg_256x128 = (int64_t)((M + 255) / 256) * n128;
   // 256x128 tile, 8 waves, 3-deep LDS ring with counted vmcnt: +5..17 % on the large-M layers (measured 1003 vs 858 TF/s
   // on the 64x64x1280 3x3 conv); smaller problems keep the 4-wave 2-stage tiles (finer granularity, same rate there)

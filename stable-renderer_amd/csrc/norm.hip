@@ -7,6 +7,8 @@
 // scale/shift in LDS and applies y = x*sc + sh (+SiLU).  Both passes can read the channel concat of two
 // sources, which is how the decoder's th.cat([h, skip]) is consumed without materialising it.
 #include "sr_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -160,6 +162,143 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
   }
 }
 
+// Single-launch GroupNorm for maps whose (batch entry, group bundle) slab fits the workgroup's registers (all UNet levels
+// up to 32x32): grid (groups/GB * B).  A workgroup owns GB consecutive groups (GB*cpg
+// channels, a multiple of one 16-byte chunk, contiguous per pixel), reads its slab ONCE into registers, reduces mean and
+// then the centred second moment through LDS in a fixed order (bit-reproducible, no E[x^2]-mean^2 cancellation), and
+// writes y = (x-mean)*rstd*gamma+beta (+SiLU).  One read + one write of the tensor and one launch instead of two reads,
+// a write, a partials round trip and two launches; the two-pass kernels above remain for large maps (VAE).
+template <typename T, int NV, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void gn_fused_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y, int HW, int C1, int C2,
+                                                         int groups, int GB, float eps, int silu) {
+  constexpr int EPC = sr_traits<T>::EPC;
+  using VEC = typename std::conditional<sizeof(T) == 2, h16x8, f32x4>::type;   // native vectors: register asm operands
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int C = C1 + C2, cpg = C / groups, span = GB * cpg, vpp = span / EPC, pp = BLOCK / vpp;
+  float* chs = (float*)smem_raw;                    // [pp][span] per-thread partials
+  float* chsum = chs + pp * span;                   // [span]
+  float* gstat = chsum + span;                      // [GB]
+  // bundles of one batch entry interleave inside the same cache lines: keep them on one XCD (one L2), close in time
+  const int nb = groups / GB, wg = sr_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wg / nb, bundle = wg - b * nb, tid = threadIdx.x;
+  const int cc = tid % vpp, ps = tid / vpp;
+  const bool active = ps < pp;
+  const int cl = cc * EPC, c0 = bundle * span + cl;         // chunk offset inside the bundle / absolute channel
+  const T* src = c0 < C1 ? x1 + (int64_t)b * HW * C1 + c0 : x2 + (int64_t)b * HW * C2 + (c0 - C1);
+  const int cs = c0 < C1 ? C1 : C2;
+  VEC raw[NV];
+  float acc[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = ps + i * pp;
+    if (active && p < HW) {
+      raw[i] = *(const VEC*)(src + (int64_t)p * cs);
+      float v[EPC];
+      load_chunk<T>((const T*)&raw[i], v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += v[e];
+    }
+  }
+  const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+  float mean_e[EPC], rstd_e[EPC];
+  // two rounds of the same fixed-order reduction: sum -> mean, centred squares -> rstd
+  for (int round = 0; round < 2; ++round) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) chs[ps * span + cl + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < span) {
+      float t = 0.f;
+      for (int q = 0; q < pp; ++q) t += chs[q * span + tid];
+      chsum[tid] = t;
+    }
+    __syncthreads();
+    if (tid < GB) {
+      float t = 0.f;
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) t += chsum[c];
+      gstat[tid] = round == 0 ? t * inv_cnt : rsqrtf(t * inv_cnt + eps);
+    }
+    __syncthreads();
+    if (round == 0) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { mean_e[e] = gstat[(cl + e) / cpg]; acc[e] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int p = ps + i * pp;
+        if (active && p < HW) {
+          float v[EPC];
+          VEC r = raw[i];
+          asm volatile("" : "+v"(r));                // keep the slab packed in registers: no hoisted fp32 copies
+          load_chunk<T>((const T*)&r, v);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { const float d = v[e] - mean_e[e]; acc[e] += d * d; }
+        }
+      }
+      __syncthreads();                               // gstat is rewritten by the next round
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) rstd_e[e] = gstat[(cl + e) / cpg];
+    }
+  }
+  if (!active) return;
+  float sc[EPC], sh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    sc[e] = rstd_e[e] * gamma[c0 + e];
+    sh[e] = beta[c0 + e] - mean_e[e] * sc[e];
+  }
+  T* dst = y + (int64_t)b * HW * C + c0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = ps + i * pp;
+    if (p < HW) {
+      float v[EPC];
+      VEC r = raw[i];
+      asm volatile("" : "+v"(r));
+      load_chunk<T>((const T*)&r, v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float t = v[e] * sc[e] + sh[e];
+        v[e] = silu ? sr_silu_f(t) : t;
+      }
+      store_chunk<T>(dst + (int64_t)p * C, v);
+    }
+  }
+}
+
+template <typename T, int NV, int BLOCK>
+void launch_gn_fused(const sr_groupnorm_args* a, int GB, hipStream_t st) {
+  constexpr int EPC = sr_traits<T>::EPC;
+  const int C = a->C1 + a->C2, span = GB * (C / a->groups), vpp = span / EPC, pp = BLOCK / vpp;
+  const size_t lds = (size_t)(pp * span + span + GB) * sizeof(float);
+  hipLaunchKernelGGL((gn_fused_kernel<T, NV, BLOCK>), dim3((a->groups / GB) * a->B), dim3(BLOCK), lds, st, (const T*)a->x, (const T*)a->x2,
+                     a->gamma, a->beta, (T*)a->y, a->HW, a->C1, a->C2, a->groups, GB, a->eps, a->silu);
+}
+
+// -> true when the fused kernel took the job
+template <typename T>
+bool try_gn_fused(const sr_groupnorm_args* a, hipStream_t st) {
+  constexpr int EPC = sr_traits<T>::EPC;
+  const int C = a->C1 + a->C2, cpg = C / a->groups;
+  int GB = 0;
+  for (int g = 1; g <= 8; ++g)
+    if ((g * cpg) % EPC == 0 && a->groups % g == 0) { GB = g; break; }
+  if (!GB) return false;
+  const int vpp = GB * cpg / EPC;
+  if (vpp > 256) return false;
+  const int need256 = sr_cdiv(a->HW, 256 / vpp), need1024 = sr_cdiv(a->HW, 1024 / vpp);
+  if (need256 <= 4) launch_gn_fused<T, 4, 256>(a, GB, st);
+  else if (need256 <= 8) launch_gn_fused<T, 8, 256>(a, GB, st);
+  else if (need1024 <= 8) launch_gn_fused<T, 8, 1024>(a, GB, st);
+  else if (need1024 <= 16) launch_gn_fused<T, 16, 1024>(a, GB, st);
+  else return false;
+  return true;
+}
+
 // one wave per row
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -225,6 +364,11 @@ extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
   const size_t lds = (size_t)(2 * C + 2 * a->groups + 16 * a->groups) * sizeof(float);
   if (lds > 64 * 1024) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C too large");
   hipStream_t st = sr_stream(stream);
+  static const bool no_fused = getenv("SR_GN_TWO_PASS") != nullptr;      // tuning / A-B aid
+  if (!no_fused && (a->dtype == SR_F16 ? try_gn_fused<_Float16>(a, st) : a->dtype == SR_F32 ? try_gn_fused<float>(a, st) : false)) {
+    SR_CHECK_LAUNCH("sr_groupnorm");
+    return SR_OK;
+  }
   dim3 grid(nchunk, a->B);
   const int cpt = C / epc, nps = 256 / cpt >= 1 ? 256 / cpt : 1;
   const size_t lds_stats = (size_t)2 * nps * C * sizeof(float);

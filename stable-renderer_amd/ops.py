@@ -58,8 +58,19 @@ def pack_bias(b, geglu=False):
     return b.contiguous()
 
 
+_WS = {}
+
+
+def workspace(device, nbytes=64 << 20):
+    """per-device fp32 scratch shared by every igemm on the stream (split-K partials; dead after each call)"""
+    key = str(device)
+    if key not in _WS:
+        _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _WS[key]
+
+
 def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C2=0, bias=None, rowvec=None,
-               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None):
+               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0):
     ar = L.IgemmArgs()
     ar.a, ar.a2, ar.w, ar.bias, ar.rowvec, ar.residual, ar.out = _p(a), _p(a2), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
     ar.zero_page = _p(zero_page(a.device))
@@ -67,6 +78,9 @@ def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C
     ar.act, ar.transpose_out, ar.ldt, ar.out_f32 = act, transpose_out, ldt, out_f32
     ar.dtype = DT[a.dtype if dtype is None else dtype]
     ar.scale = scale
+    ar.rowvec_ld = rowvec_ld
+    ws = workspace(a.device)
+    ar.workspace, ar.workspace_bytes = _p(ws), ws.numel()
     return ar
 
 

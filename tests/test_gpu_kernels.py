@@ -45,7 +45,8 @@ DTYPES = [torch.float16, torch.float32]
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", ["linear_small", "linear_big", "conv3", "conv3_stride2", "conv3_up", "conv3_cat",
-                                  "conv_cin4", "conv_n4", "geglu", "residual_rowvec", "transposed", "transposed_77"])
+                                  "conv_cin4", "conv_n4", "geglu", "residual_rowvec", "transposed", "transposed_77",
+                                  "splitk_residual_rowvec", "splitk_cat_up"])
 def test_igemm(ops, dtype, case):
     dev = "cuda"
     ke = ops.kelems(dtype)
@@ -71,6 +72,10 @@ def test_igemm(ops, dtype, case):
         N, act = 256, 2
     elif case == "residual_rowvec":
         KH, N = 3, 160
+    elif case == "splitk_residual_rowvec":                  # long K, few output tiles -> split-K + reduce epilogue
+        KH, N, C1 = 3, 160, 8 * ke
+    elif case == "splitk_cat_up":
+        KH, N, C1, C2, up, H, W = 3, 128, 6 * ke, 2 * ke, 1, 6, 5
     elif case == "transposed":
         trans, B, H, W, N = True, 2, 8, 8, 80
     elif case == "transposed_77":
@@ -86,7 +91,8 @@ def test_igemm(ops, dtype, case):
     ref = F.conv2d(xi, wr, bias, stride=stride, padding=KH // 2)
     Ho, Wo = ref.shape[2:]
     rowvec = resid = None
-    if case == "residual_rowvec":
+    rv_ld = 0
+    if case in ("residual_rowvec", "splitk_residual_rowvec"):
         rowvec = rnd(4, B, N)
         resid = rnd(5, B, N, Ho, Wo)
         ref = ref + rowvec[:, :, None, None] + resid.to(dtype).float()
@@ -118,9 +124,13 @@ def test_igemm(ops, dtype, case):
         return
     out = torch.zeros(M, nout, dtype=dtype, device=dev)
     rv = rowvec.to(dev) if rowvec is not None else None
+    if rv is not None:                                      # a slice of a wider (batched time-embedding) buffer
+        wide = torch.full((B, N + 24), 7.0, device=dev)
+        wide[:, 8:8 + N] = rv
+        rv, rv_ld = wide[:, 8:8 + N], N + 24
     rs = resid.permute(0, 2, 3, 1).reshape(M, N).contiguous().to(dtype).to(dev) if resid is not None else None
     ops.igemm(xa, wp, out, B, H, W, c1p, N, KH=KH, stride=stride, upsample=up, a2=xb, C2=C2, bias=bp, rowvec=rv,
-              residual=rs, act=act)
+              residual=rs, act=act, rowvec_ld=rv_ld)
     torch.cuda.synchronize()
     got = out.float().cpu().reshape(B, Ho, Wo, nout).permute(0, 3, 1, 2)
     close(got, ref, dtype, scale=ref.abs().max().item())
@@ -140,7 +150,12 @@ def test_igemm_out_f32_and_scale(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 70, 320, 0, True), (1, 256, 64, 64, False), (2, 33, 2560, 0, True), (1, 4096, 128, 0, True)])
+@pytest.mark.parametrize("cfg", [(2, 70, 320, 0, True), (1, 256, 64, 64, False), (2, 33, 2560, 0, True), (1, 4096, 128, 0, True),
+                                 # UNet shapes of the single-launch path (register-resident slab), incl. concat sources whose
+                                 # boundary falls inside a group, and the two-pass fallback (64x64 maps)
+                                 (2, 64, 1280, 0, True), (2, 64, 1280, 1280, True), (1, 256, 1280, 640, True),
+                                 (1, 1024, 640, 0, False), (1, 1024, 1280, 640, True), (1, 1024, 640, 320, True),
+                                 (1, 4096, 320, 0, True), (1, 4096, 640, 320, True), (1, 100, 320, 0, False)])
 def test_groupnorm(ops, dtype, cfg):
     B, HW, C1, C2, silu = cfg
     x = rnd(1, B, HW, C1 + C2) * 1.5 + 0.3

@@ -27,17 +27,35 @@ agg = defaultdict(lambda: [0.0, 0, 0.0])
 plan.run()
 torch.cuda.synchronize()
 reps = 3
+SEQ = "seq" in sys.argv          # in-sequence: the whole plan back to back, one event between ops (cold-ish caches, real order)
+seq_us = None
+if SEQ:
+    seq_us = [0.0] * plan.n
+    for _ in range(reps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(plan.n + 1)]
+        ones = [(L.Op * 1)(plan.ops[i]) for i in range(plan.n)]
+        torch.cuda.synchronize()
+        evs[0].record()
+        for i in range(plan.n):
+            lib.sr_plan_run(ones[i], 1, O.stream_ptr())
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        for i in range(plan.n):
+            seq_us[i] += evs[i].elapsed_time(evs[i + 1]) * 1e3 / reps
 for i in range(plan.n):
     op = plan.ops[i]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    one = (L.Op * 1)(op)
-    lib.sr_plan_run(one, 1, O.stream_ptr())
-    e0.record()
-    for _ in range(reps):
+    if SEQ:
+        us = seq_us[i]
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        one = (L.Op * 1)(op)
         lib.sr_plan_run(one, 1, O.stream_ptr())
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
+        e0.record()
+        for _ in range(reps):
+            lib.sr_plan_run(one, 1, O.stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
     k = op.kind
     if k == 1:
         a = op.u.igemm
@@ -58,7 +76,7 @@ for i in range(plan.n):
     agg[sig][2] += plan.op_flops[i]
 tot = sum(v[0] for v in agg.values())
 print(f"total {tot/1e3:.2f} ms over {plan.n} ops")
-for sig, (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+for sig, (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
     tf = fl / (us * 1e-6) / 1e12 if us > 0 else 0
     print(f"{us/1e3:8.3f} ms {100*us/tot:5.1f}%  n={n:3d} avg {us/n:8.1f} us {tf:7.1f} TF/s  {sig}")
 bykind = defaultdict(float)
