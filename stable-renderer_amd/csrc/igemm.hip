@@ -20,7 +20,7 @@ namespace {
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
-                                                                        const int NT, const int nwg) {
+                                                                        const int NT, const int nwg, const int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KE = 128 / (int)sizeof(T);            // elements of K per step
   constexpr int NW = WAVES_M * WAVES_N;               // waves per workgroup (4 or 8)
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = sr_xcd_remap(blockIdx.x, nwg);
+  const int wg = tile0 + sr_xcd_remap(blockIdx.x, nwg);      // this launch covers tiles [tile0, tile0 + nwg)
   const int mt = wg / NT, nt = wg - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
   const int lrow = lane >> 3;
@@ -175,18 +175,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   const int N = p.N;
   const int ldr = p.rowvec_ld ? p.rowvec_ld : N;
   if constexpr (SPLIT) {
-    float* ws = (float*)p.workspace + (int64_t)blockIdx.y * M * N;
+    // fragment-major partials: ws[z][tile][wave][tn][tm][lane] (float4) -> every store instruction writes 1 KiB contiguous
+    f32x4* ws = (f32x4*)p.workspace + (((int64_t)blockIdx.y * nwg + (wg - tile0)) * NW + wv) * (TN * TM * 64) + lane;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int m = m0 + pm0 + tm * 16 + c16;
-      if (m >= M) continue;
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + qn0 + tn * 16 + 4 * g4;
-        if (n >= N) continue;                              // N % 4 == 0 on this path
-        *(f32x4*)(ws + (int64_t)m * N + n) = acc[tn][tm];
-      }
-    }
+      for (int tm = 0; tm < TM; ++tm) ws[(tn * TM + tm) * 64] = acc[tn][tm];
     return;
   } else if constexpr (!TRANS) {
     const int ldo = (p.act == 2) ? (N >> 1) : N;
@@ -365,21 +359,30 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   (void)NT;
-  hipLaunchKernelGGL(k, dim3(nwg), dim3(WAVES_M * WAVES_N * 64), lds, st, a, M, Ho, Wo, NTv, nwg);
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(WAVES_M * WAVES_N * 64), lds, st, a, M, Ho, Wo, NTv, nwg, 0);
   SR_CHECK_LAUNCH("sr_igemm");
   return SR_OK;
 }
 
-// out = act(scale * sum_z ws[z] + bias + rowvec) + residual, 4 consecutive channels per thread, fixed z order
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const sr_igemm_args p, const int M, const int rpb, const int S) {
-  const int N = p.N, n4 = N >> 2;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)M * n4) return;
-  const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) * 4;
-  const float* ws = (const float*)p.workspace + (int64_t)m * N + n;
-  f32x4 acc = *(const f32x4*)ws;
-  for (int z = 1; z < S; ++z) { const f32x4 t = *(const f32x4*)(ws + (int64_t)z * M * N); acc += t; }
+// out = act(scale * sum_z ws[z] + bias + rowvec) + residual for the tiles [tile0, tile0+nwg) of a split launch; a block
+// owns one (tn, tm) fragment of each of the tile's 4 waves and reads the partials in the layout the GEMM wrote (1 KiB
+// per wave instruction), fixed z order.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const sr_igemm_args p, const int M, const int rpb, const int S,
+                                                            const int NT, const int nwg, const int tile0) {
+  constexpr int TM = BM / 2 / 16, TN = BN / 2 / 16, FR = TN * TM;
+  const int tile_l = blockIdx.x / FR, fr = blockIdx.x - tile_l * FR;
+  const int tn = fr / TM, tm = fr - tn * TM;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c16 = lane & 15, g4 = lane >> 4;
+  const int wg = tile0 + tile_l, mt = wg / NT, nt = wg - mt * NT;
+  const int m = mt * BM + (wv >> 1) * (BM / 2) + tm * 16 + c16;
+  const int n = nt * BN + (wv & 1) * (BN / 2) + tn * 16 + 4 * g4;
+  const int N = p.N;
+  if (m >= M || n >= N) return;
+  const f32x4* ws = (const f32x4*)p.workspace + ((int64_t)tile_l * 4 + wv) * (FR * 64) + fr * 64 + lane;
+  const int64_t zs = (int64_t)nwg * 4 * FR * 64;
+  f32x4 acc = ws[0];
+  for (int z = 1; z < S; ++z) acc += ws[z * zs];
   float v[4] = {acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale};
   if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
   if (p.rowvec) {
@@ -404,18 +407,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sr_igemm_args 
   else { h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; *(h16x4*)((_Float16*)p.out + oi) = hv; }
 }
 
+// tiles [0, tile0) full-K (ordinary epilogue), tiles [tile0, ntiles) split S ways over K + reduce
 template <typename T, int BM, int BN>
-int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int S, hipStream_t st) {
-  const int MT = (M + BM - 1) / BM, NTv = (a.N + BN - 1) / BN, nwg = MT * NTv;
-  constexpr int lds = 2 * (BM + BN) * 128;
-  auto k = igemm_kernel<T, BM, BN, 2, 2, 2, false, true>;
+int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int tile0, int S, hipStream_t st) {
+  const int MT = (M + BM - 1) / BM, NTv = (a.N + BN - 1) / BN, ntiles = MT * NTv, ntail = ntiles - tile0;
+  constexpr int lds_stage = 2 * (BM + BN) * 128;
+  constexpr int lds_epi = 4 * (BM / 2) * ((BN / 2) * 4 + 16);
+  constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+  auto kf = igemm_kernel<T, BM, BN, 2, 2, 2, false, false>;
+  auto ks = igemm_kernel<T, BM, BN, 2, 2, 2, false, true>;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
-  hipLaunchKernelGGL(k, dim3(nwg, S), dim3(256), lds, st, a, M, Ho, Wo, NTv, nwg);
-  const int64_t quads = (int64_t)M * (a.N >> 2);
-  hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a, M, Ho * Wo, S);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  if (tile0 > 0) hipLaunchKernelGGL(kf, dim3(tile0), dim3(256), lds, st, a, M, Ho, Wo, NTv, tile0, 0);
+  hipLaunchKernelGGL(ks, dim3(ntail, S), dim3(256), lds, st, a, M, Ho, Wo, NTv, ntail, tile0);
+  constexpr int FR = (BM / 32) * (BN / 32);
+  hipLaunchKernelGGL((splitk_reduce_kernel<T, BM, BN>), dim3(ntail * FR), dim3(256), 0, st, a, M, Ho * Wo, S, NTv, ntail, tile0);
   SR_CHECK_LAUNCH("sr_igemm(split-K)");
   return SR_OK;
+}
+
+// Wave quantisation model for the 4-wave tiles (calibrated on MI355X): `slots` workgroups are co-resident
+// chip-wide, a round of co-resident workgroups takes t_k microseconds per K-step, partials cost their HBM round trip.
+// Returns the split count for the tail round (1 = none) and sets tile0 (tiles before it run unsplit).
+static inline int plan_split(int64_t tiles, int KT, int slots, double t_k, int64_t tile_ws_bytes, int64_t ws_bytes, int* tile0) {
+  const int64_t full = tiles / slots, tail = tiles - full * slots;
+  *tile0 = (int)(full * slots);
+  if (tail == 0) return 1;
+  double best = (double)KT * t_k;                            // the tail as one more (partly empty) round
+  int bestS = 1;
+  for (int S = 2; S <= 16; ++S) {
+    if (KT / S < 8 || (int64_t)S * tail * tile_ws_bytes > ws_bytes) break;
+    const int64_t rounds = (tail * S + slots - 1) / slots;
+    const double t = (double)rounds * ((KT + S - 1) / S) * t_k + (double)(2 * S * tail * tile_ws_bytes) / 4.0e6 + 14.0;   // + two more launches
+    if (t < best * 0.9) { best = t; bestS = S; }
+  }
+  return bestS;
 }
 
 template <typename T, bool TRANS>
@@ -427,28 +457,28 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   if (force == 2) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 3) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 4) return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
-  // split-K: a long-K conv whose output has too few tiles for 256 CUs (8x8 / 16x16 UNet levels: 80 / 320 tiles of
-  // 128x128).  S splits of K run as grid.y, fp32 partials go through the caller's workspace and a fixed-order reduce
-  // kernel applies the epilogue (bit-reproducible; no float atomics).
+  const int64_t wg_256x128 = (int64_t)((M + 255) / 256) * n128;
+  const bool big = !waste128 && wg_256x128 >= 512;
+  // split-K of the last, partly empty round of workgroups (all of them when the whole grid is less than one round: the
+  // 8x8 / 16x16 UNet levels).  fp32 partials go through the caller's workspace; a fixed-order reduce kernel applies the
+  // epilogue (bit-reproducible, no float atomics).
   if constexpr (!TRANS) {
     const int KT = a.KH * a.KH * ((a.C1 + a.C2) / (int)(128 / sizeof(T)));
-    const char* senv = getenv("SR_SPLITK");                  // tuning aid: 0 = off, else the target workgroup count
-    const int target = senv ? atoi(senv) : 512;
-    if (force == 0 && target > 0 && a.workspace && a.act != 2 && a.N % 4 == 0 && KT >= 64) {
-      const int64_t tiles = waste128 ? (int64_t)((M + 127) / 128) * n64 : wg_128x128;
-      if (tiles * 2 <= target + target / 2) {
-        int S = (int)((target + tiles / 2) / tiles);
-        if (S > KT / 16) S = KT / 16;
-        const int64_t per = (int64_t)M * a.N * 4;
-        if ((int64_t)S * per > a.workspace_bytes) S = (int)(a.workspace_bytes / per);
-        if (S >= 2) return waste128 ? launch_split<T, 128, 64>(a, M, Ho, Wo, S, st) : launch_split<T, 128, 128>(a, M, Ho, Wo, S, st);
+    static const bool off = getenv("SR_SPLITK") && atoi(getenv("SR_SPLITK")) == 0;      // tuning / A-B aid
+    if (force == 0 && !off && !big && a.workspace && a.act != 2 && a.N % 4 == 0 && KT >= 32) {
+      int tile0 = 0;
+      if (!waste128) {
+        const int S = plan_split(wg_128x128, KT, 512, 1.2, 128 * 128 * 4, a.workspace_bytes, &tile0);
+        if (S > 1) return launch_split<T, 128, 128>(a, M, Ho, Wo, tile0, S, st);
+      } else {
+        const int S = plan_split((int64_t)((M + 127) / 128) * n64, KT, 768, 0.93, 128 * 64 * 4, a.workspace_bytes, &tile0);
+        if (S > 1) return launch_split<T, 128, 64>(a, M, Ho, Wo, tile0, S, st);
       }
     }
   }
-  const int64_t wg_256x128 = (int64_t)((M + 255) / 256) * n128;
   // 256x128 tile, 8 waves, 3-deep LDS ring with counted vmcnt: +5..17 % on the large-M layers (measured 1003 vs 858 TF/s
   // on the 64x64x1280 3x3 conv); smaller problems keep the 4-wave 2-stage tiles (finer granularity, same rate there)
-  if (force == 1 || (force == 0 && !waste128 && wg_256x128 >= 512))
+  if (force == 1 || (force == 0 && big))
     return launch<T, 256, 128, 4, 2, 3, TRANS>(a, M, Ho, Wo, st);
   // (a 128x160 tile for N = 320 measured slower than five 64-wide tiles on MI355X: 487 vs 612 TF/s on the 3x3 conv)
   if (!waste128 && wg_128x128 >= 192) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);

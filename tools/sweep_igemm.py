@@ -30,8 +30,19 @@ shapes = [
     (65536, 1, 1, 320, 2560, 1, 0),
     (16, 8, 8, 1280, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 32, 32, 640, 640, 3, 0), (16, 64, 64, 320, 320, 3, 0),
 ]
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] != "splitk":
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+if len(sys.argv) > 1 and sys.argv[1] == "splitk":
+    os.environ.pop("SR_IGEMM_TILE", None)
+    for sh in [(16, 8, 8, 1280, 1280, 3, 0), (16, 8, 8, 2560, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 16, 16, 2560, 1280, 3, 0),
+               (16, 16, 16, 1920, 1280, 3, 0), (16, 32, 32, 640, 640, 3, 0), (16, 32, 32, 1280, 640, 3, 0), (16, 32, 32, 1920, 640, 3, 0)]:
+        row = []
+        for target in (0, 384, 512, 768, 1024, 1536, 2048):
+            os.environ["SR_SPLITK"] = str(target)
+            us, tf = run(*sh)
+            row.append(f"s{target}:{us:6.1f}us {tf:5.0f}TF")
+        print("B%d %dx%d C%d N%d k%d act%d | " % sh + " | ".join(row), flush=True)
+    sys.exit(0)
 for sh in shapes:
     row = []
     for tile in (0, 1, 2, 3, 4):
