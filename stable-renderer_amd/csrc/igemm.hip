@@ -191,12 +191,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
       // (the staging buffers are free now) so that global stores -- and the residual loads -- are whole 16-byte
       // chunks of contiguous rows instead of 4..8-byte pieces scattered over 16 rows per instruction.
       constexpr int WCOLS = BN / WAVES_N;                    // columns of this wave's sub-tile before GEGLU
+      // rows of the wave's sub-tile staged per pass: all of them when that fits the staging LDS, else 16 (the 256x320 tile)
+      constexpr int TMP = (NW * (BM / WAVES_M) * (WCOLS * 4 + 16) <= STAGES * STAGE_BYTES) ? TM : 1;
       const int ocols = (p.act == 2) ? WCOLS / 2 : WCOLS;
       const int rowb = ocols * oes + 16;                     // padded LDS row (bank spread, keeps 16-B alignment)
       __syncthreads();                                       // every wave is done reading the staging tiles
-      char* wl = smem + wv * ((BM / WAVES_M) * rowb);
+      char* wl = smem + wv * ((TMP * 16) * rowb);
+      const int cpr = ocols * oes / 16;                      // 16-B chunks per row
+      const int rpi = 64 / cpr;                              // rows per wave instruction
+      const int lr = lane / cpr, lc = lane - lr * cpr;
+      const int ncol0 = (p.act == 2) ? ((n0 + qn0) >> 1) : (n0 + qn0);
+      const int epc_o = 16 / oes;
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
+     for (int tm0 = 0; tm0 < TM; tm0 += TMP) {
+#pragma unroll
+      for (int tm = tm0; tm < tm0 + TMP; ++tm) {
         const int m = m0 + pm0 + tm * 16 + c16;
         const int b = (m < M) ? m / rpb : 0;
 #pragma unroll
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
           if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
           else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
           else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
-          char* dst = wl + (tm * 16 + c16) * rowb;
+          char* dst = wl + ((tm - tm0) * 16 + c16) * rowb;
           if (p.act == 2) {
             const float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
             const int col = tn * 8 + 2 * g4;
@@ -226,15 +235,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
       // read back row-wise (same wave wrote it: no block barrier needed, only the LDS write->read ordering)
       __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
       __builtin_amdgcn_wave_barrier();
-      const int cpr = ocols * oes / 16;                      // 16-B chunks per row
-      const int rpi = 64 / cpr;                              // rows per wave instruction
-      const int lr = lane / cpr, lc = lane - lr * cpr;
-      const int ncol0 = (p.act == 2) ? ((n0 + qn0) >> 1) : (n0 + qn0);
-      const int epc_o = 16 / oes;
-      for (int r0 = 0; r0 < BM / WAVES_M; r0 += rpi) {
+      for (int r0 = 0; r0 < TMP * 16; r0 += rpi) {
         const int row = r0 + lr;
-        if (lr >= rpi || row >= BM / WAVES_M) continue;
-        const int m = m0 + pm0 + row, ncol = ncol0 + lc * epc_o;
+        if (lr >= rpi || row >= TMP * 16) continue;
+        const int m = m0 + pm0 + tm0 * 16 + row, ncol = ncol0 + lc * epc_o;
         if (m >= M || ncol >= ldo) continue;
         uint4 raw = *(const uint4*)(wl + row * rowb + lc * 16);
         const int64_t oi = (int64_t)m * ldo + ncol;
@@ -261,6 +265,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
         }
         *(uint4*)((char*)p.out + oi * oes) = raw;
       }
+      __builtin_amdgcn_wave_barrier();                       // (LDS is in order per wave: the next pass may overwrite)
+     }
       return;
     }
 #pragma unroll
@@ -353,7 +359,8 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int NTv = (a.N + BN - 1) / BN;
   const int nwg = MT * NTv;
   constexpr int lds_stage = STAGES * (BM + BN) * 128;
-  constexpr int lds_epi = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);   // fp32 output sub-tiles of all waves
+  constexpr int lds_epi_all = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);   // fp32 output sub-tiles of all waves
+  constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
   constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
   auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS>;
   static bool attr_set = false;
@@ -457,6 +464,14 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   if (force == 2) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 3) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 4) return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if constexpr (!TRANS && sizeof(T) == 2) {
+    // 256x320 tile (8 waves, 64x160 per wave): every UNet layer width is a multiple of 320, so no padded columns, the
+    // activation tile is fetched once for N = 320, and 142 FLOP per byte staged through the 64 B/clk TCP->LDS path (a
+    // 128x128 tile: 64 FLOP/B = exactly the MFMA rate, so that path saturates first).  Needs a full round of workgroups:
+    // measured 830 vs 627 TF/s on the 64x64 C320 3x3 conv, 1086 vs 1000 on C1280, but 556 vs 678 at 32x32 C640.
+    if (force == 5 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) >= 256))
+      return launch<T, 256, 320, 4, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  }
   const int64_t wg_256x128 = (int64_t)((M + 255) / 256) * n128;
   const bool big = !waste128 && wg_256x128 >= 512;
   // split-K of the last, partly empty round of workgroups (all of them when the whole grid is less than one round: the

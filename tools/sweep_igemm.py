@@ -23,6 +23,7 @@ def run(B, H, W, C, N, KH, act=0, reps=20):
     ms = e0.elapsed_time(e1) / reps
     return ms * 1e3, 2.0 * B * H * W * N * KH * KH * C / ms / 1e9
 
+TILES = (0, 1, 2, 3, 4)
 shapes = [
     (65536, 1, 1, 64, 320, 1, 0), (65536, 1, 1, 320, 320, 1, 0), (65536, 1, 1, 640, 320, 1, 0), (65536, 1, 1, 1280, 320, 1, 0),
     (16384, 1, 1, 640, 640, 1, 0), (4096, 1, 1, 1280, 1280, 1, 0),
@@ -30,8 +31,15 @@ shapes = [
     (65536, 1, 1, 320, 2560, 1, 0),
     (16, 8, 8, 1280, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 32, 32, 640, 640, 3, 0), (16, 64, 64, 320, 320, 3, 0),
 ]
-if len(sys.argv) > 1 and sys.argv[1] != "splitk":
+if len(sys.argv) > 1 and sys.argv[1] not in ("splitk", "t5"):
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+if len(sys.argv) > 1 and sys.argv[1] == "t5":
+    TILES = (0, 1, 5)
+    shapes = [(65536, 1, 1, 320, 320, 1, 0), (65536, 1, 1, 1280, 320, 1, 0), (16, 64, 64, 320, 320, 3, 0), (16, 64, 64, 640, 320, 3, 0),
+              (65536, 1, 1, 320, 2560, 1, 2), (16384, 1, 1, 640, 5120, 1, 2), (4096, 1, 1, 1280, 10240, 1, 2),
+              (16384, 1, 1, 640, 640, 1, 0), (16384, 1, 1, 2560, 640, 1, 0), (16, 32, 32, 640, 640, 3, 0), (16, 32, 32, 1280, 640, 3, 0),
+              (4096, 1, 1, 1280, 1280, 1, 0), (4096, 1, 1, 5120, 1280, 1, 0), (16, 16, 16, 1280, 1280, 3, 0),
+              (16, 64, 64, 1280, 1280, 3, 0), (16, 64, 64, 640, 640, 3, 0)]
 if len(sys.argv) > 1 and sys.argv[1] == "splitk":
     os.environ.pop("SR_IGEMM_TILE", None)
     for sh in [(16, 8, 8, 1280, 1280, 3, 0), (16, 8, 8, 2560, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 16, 16, 2560, 1280, 3, 0),
@@ -45,7 +53,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "splitk":
     sys.exit(0)
 for sh in shapes:
     row = []
-    for tile in (0, 1, 2, 3, 4):
+    for tile in TILES:
         if tile:
             os.environ["SR_IGEMM_TILE"] = str(tile)
         else:
