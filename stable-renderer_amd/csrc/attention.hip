@@ -11,13 +11,17 @@
 // pass exists anywhere.  fp16: v_mfma_f32_16x16x32_f16, fp32: v_mfma_f32_16x16x4_f32 (exact), fp32 softmax.
 #include "sr_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
 constexpr int KV_TILE = 64;     // keys per iteration (4 MFMA key tiles)
 
-template <typename T, int DQ, int DT, int QT>
-__global__ __launch_bounds__(256, (QT <= 2 && DT <= 5 && sizeof(T) == 2) ? 2 : 1) void attn_kernel(const sr_attention_args p) {
+// SR ("sum row"): when d is not a multiple of 16 the last V^T tile has spare rows; row d is filled with ones, so the MFMA
+// that accumulates O^T also accumulates the softmax denominator (of the SAME fp16-rounded probabilities as the numerator)
+// and the per-element v_add of the row sum disappears from the VALU-bound d=40 loop.
+template <typename T, int DQ, int DT, int QT, bool SR, int MB>
+__global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p) {
   constexpr int EPC = sr_traits<T>::EPC;
   constexpr int NCH = 4 * DQ;                               // 16-B chunks per K row in LDS (zero padded)
   constexpr int KROW = NCH * 16;                            // bytes
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(256, (QT <= 2 && DT <= 5 && sizeof(T) == 2) ? 2 : 1
       const int key = k0 + ch * EPC;
       rv[i] = make_uint4(0, 0, 0, 0);
       if (idx < DT * 16 * VCH && row < d && key < p.ldt) rv[i] = *(const uint4*)(vbase + (int64_t)row * p.ldt + key);
+      if constexpr (SR) { if (row == d) rv[i] = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u); }   // fp16 ones
     }
   };
   auto lstore = [&](int buf) {
@@ -164,15 +169,18 @@ __global__ __launch_bounds__(256, (QT <= 2 && DT <= 5 && sizeof(T) == 2) ? 2 : 1
         const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);           // first tile: exp2(-inf) = 0
         mrow[qt] = mnew;
         float ps = 0.f;
+        const f32x2 sl2v = {sl2, sl2}, nmv = {-mnew, -mnew};
   #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
   #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], sl2, -mnew));   // raw v_exp_f32 (args <= 0)
-            s[kt][qt][r] = e;
-            ps += e;
+          for (int r = 0; r < 4; r += 2) {
+            f32x2 t = {s[kt][qt][r], s[kt][qt][r + 1]};
+            t = __builtin_elementwise_fma(t, sl2v, nmv);          // v_pk_fma_f32: two scores per VALU op
+            const float e0 = __builtin_amdgcn_exp2f(t[0]), e1 = __builtin_amdgcn_exp2f(t[1]);   // raw v_exp_f32 (args <= 0)
+            s[kt][qt][r] = e0; s[kt][qt][r + 1] = e1;
+            if constexpr (!SR) ps += e0 + e1;
           }
-        lrow[qt] = lrow[qt] * alpha + ps;
+        if constexpr (!SR) lrow[qt] = lrow[qt] * alpha + ps;
         if (__any(alpha != 1.0f)) {                            // wave-uniform: most tiles leave every row max unchanged
   #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
@@ -230,8 +238,12 @@ __global__ __launch_bounds__(256, (QT <= 2 && DT <= 5 && sizeof(T) == 2) ? 2 : 1
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float l = lrow[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    if constexpr (SR) {
+      l = __shfl(o[DT - 1][qt][0], (((d & 15) >> 2) << 4) + c16);   // O^T row d (the ones row) of this lane's query column
+    } else {
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+    }
     const float inv = 1.0f / l;
     const int q = q0 + qt * 16 + c16;
     if (q >= p.Tq) continue;
@@ -251,12 +263,288 @@ __global__ __launch_bounds__(256, (QT <= 2 && DT <= 5 && sizeof(T) == 2) ? 2 : 1
   }
 }
 
-template <typename T, int DQ, int DT, int QT>
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined fp16 variant (QT = 2) for the small head dims of the 64x64 / 32x32 UNet levels, where the loop is
+// bound by the softmax VALU work and by dependency latency, not by MFMA rate (d = 40: 160 MFMA FLOP but ~4 VALU ops per
+// score).  Each wave overlaps the two inside ITS OWN instruction stream, because an in-order wave cannot rely on its one
+// SIMD partner to fill every stall:
+//   phase A(t):  S(t+1) = K(t+1) Q^T  [MFMA]   interleaved with   P(t) = exp2(S(t)*c - m)  -> fp16   [VALU]
+//   phase B(t):  O += V(t)^T P(t)     [MFMA]   interleaved with   row max / alpha of S(t+1)           [VALU + 2 shuffles]
+// S lives in two register sets that swap roles every tile (loop unrolled by two); K/V tiles go through a 3-slot LDS ring
+// (tile t+2 is written while t and t+1 are read) with ONE barrier per tile; global loads run one more tile ahead in
+// registers.  The interleave itself is requested with sched_group_barrier (1 MFMA : n VALU).
+template <int DQ, int DT, bool SR>
+__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const sr_attention_args p) {
+  using T = _Float16;
+  constexpr int EPC = 8, QT = 2;
+  constexpr int NCH = 4 * DQ, KROW = NCH * 16, VROW = KV_TILE * 2 + 8, VCH = KV_TILE * 2 / 16;
+  constexpr int K_BYTES = KV_TILE * KROW, V_BYTES = DT * 16 * VROW, TILE_B = K_BYTES + V_BYTES;
+  constexpr int KPT = (KV_TILE * NCH + 255) / 256, VPT = (DT * 16 * VCH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int bk = p.Bk == 1 ? 0 : b;
+  const int d = p.d, Tk = p.Tk;
+  const int q0 = blockIdx.x * (64 * QT) + wv * (16 * QT);
+  const int NT = (Tk + KV_TILE - 1) / KV_TILE;
+
+  uint4 qf[QT][DQ];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = q0 + qt * 16 + c16;
+#pragma unroll
+    for (int st = 0; st < DQ; ++st) {
+      const int di = st * 4 * EPC + g4 * EPC;
+      qf[qt][st] = make_uint4(0, 0, 0, 0);
+      if (q < p.Tq && di < d) qf[qt][st] = *(const uint4*)((const T*)p.q + ((int64_t)b * p.Tq + q) * p.q_stride + h * d + di);
+    }
+  }
+  f32x4 o[DT][QT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrow[QT], lrow[QT], alpha[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) { mrow[qt] = -INFINITY; lrow[qt] = 0.f; alpha[qt] = 1.f; }
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  // ---- per-thread load slots (loop invariant): which K / V^T chunk this thread moves every tile
+  const T* kbase = (const T*)p.k + (int64_t)bk * Tk * p.k_stride + h * d;
+  const T* vbase = (const T*)p.vt + ((int64_t)bk * p.heads + h) * (int64_t)d * p.ldt;
+  int k_key[KPT], k_lds[KPT], k_el[KPT]; bool k_ok[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int idx = tid + i * 256, key = idx / NCH, ch = idx - key * NCH;
+    k_key[i] = key; k_el[i] = ch * EPC;
+    k_ok[i] = idx < KV_TILE * NCH && ch * EPC < d;
+    k_lds[i] = idx < KV_TILE * NCH ? key * KROW + ((NCH == 8) ? (ch ^ (key & 7)) : ch) * 16 : -1;
+  }
+  const T* v_src[VPT]; int v_lds[VPT], v_k8[VPT]; bool v_ok[VPT], v_one[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int idx = tid + i * 256, row = idx / VCH, ch = idx - row * VCH;
+    v_ok[i] = idx < DT * 16 * VCH && row < d;
+    v_one[i] = SR && row == d;
+    v_lds[i] = idx < DT * 16 * VCH ? K_BYTES + row * VROW + ch * 16 : -1;
+    v_k8[i] = ch * EPC;
+    v_src[i] = vbase + (int64_t)(row < d ? row : 0) * p.ldt;
+  }
+  uint4 rk[KPT], rv[VPT];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int key = min(k0 + k_key[i], Tk - 1);            // rows past Tk: any valid row, their scores are masked to -inf
+      rk[i] = make_uint4(0, 0, 0, 0);
+      if (k_ok[i]) rk[i] = *(const uint4*)(kbase + (int64_t)key * p.k_stride + k_el[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int key = min(k0 + v_k8[i], p.ldt - EPC);        // columns past Tk meet p = 0
+      rv[i] = v_one[i] ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u) : make_uint4(0, 0, 0, 0);
+      if (v_ok[i]) rv[i] = *(const uint4*)(v_src[i] + key);
+    }
+  };
+  auto lstore = [&](int slot) {
+    char* bs = smem + slot * TILE_B;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) if (k_lds[i] >= 0) *(uint4*)(bs + k_lds[i]) = rk[i];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) if (v_lds[i] >= 0) *(uint4*)(bs + v_lds[i]) = rv[i];
+  };
+
+  // ---- pipeline pieces
+  auto qk = [&](f32x4 (&s)[4][QT], int slot) {
+    const char* cK = smem + slot * TILE_B;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < DQ; ++st) {
+      uint4 kf[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int key = kt * 16 + c16, ch = 4 * st + g4;
+        kf[kt] = *(const uint4*)(cK + key * KROW + ((NCH == 8) ? (ch ^ (key & 7)) : ch) * 16);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sr_mma(s[kt][qt], kf[kt], qf[qt][st], T());
+    }
+  };
+  // row max of a fresh S tile -> running max, alpha (applied to O and l at the start of the next iteration)
+  auto rowmax = [&](f32x4 (&s)[4][QT], int k0, bool mask) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if (mask) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + 4 * g4 + r >= Tk) s[kt][qt][r] = -INFINITY;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(mrow[qt], mx * sl2);
+      alpha[qt] = __builtin_amdgcn_exp2f(mrow[qt] - mnew);
+      mrow[qt] = mnew;
+    }
+  };
+  // P = exp2(S*c - m) packed to the fp16 B-operand layout of the PV product
+  auto expo = [&](f32x4 (&s)[4][QT], uint4 (&pf)[2][QT]) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const f32x2 sl2v = {sl2, sl2}, nmv = {-mrow[qt], -mrow[qt]};
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          f32x2 t = {s[kt][qt][r], s[kt][qt][r + 1]};
+          t = __builtin_elementwise_fma(t, sl2v, nmv);
+          const float e0 = __builtin_amdgcn_exp2f(t[0]), e1 = __builtin_amdgcn_exp2f(t[1]);
+          s[kt][qt][r] = e0; s[kt][qt][r + 1] = e1;
+          if constexpr (!SR) ps += e0 + e1;
+        }
+      if constexpr (!SR) lrow[qt] += ps;
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp) {
+        h16x8 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { hv[r] = (_Float16)s[2 * kp][qt][r]; hv[4 + r] = (_Float16)s[2 * kp + 1][qt][r]; }
+        pf[kp][qt] = __builtin_bit_cast(uint4, hv);
+      }
+    }
+  };
+  auto rescale = [&]() {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if constexpr (!SR) lrow[qt] *= alpha[qt];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { o[dt][qt][0] *= alpha[qt]; o[dt][qt][1] *= alpha[qt]; o[dt][qt][2] *= alpha[qt]; o[dt][qt][3] *= alpha[qt]; }
+    }
+  };
+  auto pv = [&](const uint4 (&pf)[2][QT], int slot) {
+    const char* cV = smem + slot * TILE_B + K_BYTES;
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const char* vr = cV + (dt * 16 + c16) * VROW + kp * 64 + g4 * 8;
+        const uint2 lo = *(const uint2*)vr;
+        const uint2 hi = *(const uint2*)(vr + 32);
+        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sr_mma(o[dt][qt], vf, pf[kp][qt], T());
+      }
+  };
+
+  // ---- prologue: tiles 0..2 into the ring, tile 3 in registers, S(0) and its row max
+  gload(0); lstore(0);
+  if (NT > 1) { gload(KV_TILE); lstore(1); }
+  if (NT > 2) { gload(2 * KV_TILE); lstore(2); }
+  if (NT > 3) gload(3 * KV_TILE);
+  __syncthreads();
+  f32x4 sA[4][QT], sB[4][QT];
+  qk(sA, 0);
+  rowmax(sA, 0, NT == 1);
+
+  int slot = 0;                                              // ring slot of tile t
+  // STEADY: tile t+1 exists and is a full tile (compile-time straight-line body); otherwise wave-uniform run-time flags
+  auto iter = [&](f32x4 (&sc)[4][QT], f32x4 (&sn)[4][QT], int t, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    const bool has_next = STEADY || t + 1 < NT, mask = !STEADY && t + 2 == NT;
+    const int s1 = slot == 2 ? 0 : slot + 1, s2 = slot == 0 ? 2 : slot - 1;      // slots of tiles t+1 and t+2 (= t-1)
+    if (t > 0) {
+      __syncthreads();                                       // every wave is past iteration t-1: slot s2 is free, tile t+1 visible
+      if (t + 2 < NT) lstore(s2);
+      if (t + 3 < NT) gload((t + 3) * KV_TILE);
+    }
+    uint4 pf[2][QT];
+    rescale();                                               // alpha of tile t (from the previous iteration's rowmax)
+    if (has_next) qk(sn, s1);
+    expo(sc, pf);
+    if constexpr (STEADY) {
+#pragma unroll
+      for (int i = 0; i < 4 * QT * DQ; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+      }
+    }
+    pv(pf, slot);
+    if (has_next) rowmax(sn, (t + 1) * KV_TILE, mask);
+    if constexpr (STEADY) {
+#pragma unroll
+      for (int i = 0; i < 2 * DT * QT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 1);
+      }
+    }
+    slot = s1;
+  };
+  int t = 0;
+  for (; t + 3 < NT; t += 2) {                               // both iterations have a full next tile
+    iter(sA, sB, t, std::true_type{});
+    iter(sB, sA, t + 1, std::true_type{});
+  }
+  for (bool cur_a = true; t < NT; ++t, cur_a = !cur_a) {
+    if (cur_a) iter(sA, sB, t, std::false_type{});
+    else       iter(sB, sA, t, std::false_type{});
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l;
+    if constexpr (SR) {
+      l = __shfl(o[DT - 1][qt][0], (((d & 15) >> 2) << 4) + c16);
+    } else {
+      l = lrow[qt];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+    }
+    const float inv = 1.0f / l;
+    const int q = q0 + qt * 16 + c16;
+    if (q >= p.Tq) continue;
+    T* orow = (T*)p.o + ((int64_t)b * p.Tq + q) * p.q_stride + h * d;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int di = dt * 16 + 4 * g4;
+      if (di >= d) continue;
+      h16x4 hv = {(_Float16)(o[dt][qt][0] * inv), (_Float16)(o[dt][qt][1] * inv), (_Float16)(o[dt][qt][2] * inv),
+                  (_Float16)(o[dt][qt][3] * inv)};
+      *(h16x4*)(orow + di) = hv;
+    }
+  }
+}
+
+template <int DQ, int DT, bool SR>
+int launch_pipe(const sr_attention_args& a, hipStream_t st) {
+  dim3 grid(sr_cdiv(a.Tq, 128), a.heads, a.B);
+  constexpr int lds = 3 * (KV_TILE * 4 * DQ * 16 + DT * 16 * (KV_TILE * 2 + 8));
+  auto k = attn_pipe_kernel<DQ, DT, SR>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  SR_CHECK_LAUNCH("sr_attention");
+  return SR_OK;
+}
+
+template <typename T, int DQ, int DT, int QT, bool SR = false, int MB = ((QT <= 2 && DT <= 5 && sizeof(T) == 2) ? 2 : 1)>
 int launch(const sr_attention_args& a, hipStream_t st) {
   dim3 grid(sr_cdiv(a.Tq, 64 * QT), a.heads, a.B);
   constexpr int tile_b = KV_TILE * 4 * DQ * 16 + DT * 16 * (KV_TILE * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16));
   constexpr int lds = (2 * tile_b <= 144 * 1024) ? 2 * tile_b : tile_b;
-  auto k = attn_kernel<T, DQ, DT, QT>;
+  auto k = attn_kernel<T, DQ, DT, QT, SR, MB>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
@@ -279,7 +567,13 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
     if (d <= 32) return launch<_Float16, 1, 2, 4>(*a, st);
     // QT = 2 (32 queries per wave): everything fits in 128 VGPRs -> no AGPR<->VGPR copies around the softmax and two
     // workgroups per CU, so one wave's MFMAs overlap the other's exp/max/sum VALU work
-    if (d <= 48) return launch<_Float16, 2, 3, 2>(*a, st);
+    static const bool pipe = !(getenv("SR_ATTN_PIPE") && atoi(getenv("SR_ATTN_PIPE")) == 0);   // A-B aid
+    if (d <= 48) {
+      // long key sequences (64x64 self-attention): the software-pipelined loop, 819 vs 895 us (Bk=1) / 722 vs 815 (Bk=B) at
+      // B16 T4096 d40; short ones (the 77-token prompt) stay on the simple loop, whose prologue is cheaper
+      if (pipe && a->Tk >= 512) return (d & 15) ? launch_pipe<2, 3, true>(*a, st) : launch_pipe<2, 3, false>(*a, st);
+      return (d & 15) ? launch<_Float16, 2, 3, 2, true>(*a, st) : launch<_Float16, 2, 3, 2>(*a, st);
+    }
     if (d <= 64) return launch<_Float16, 2, 4, 2>(*a, st);
     if (d <= 80) return launch<_Float16, 3, 5, 2>(*a, st);
     if (d <= 160) return launch<_Float16, 5, 10, 2>(*a, st);

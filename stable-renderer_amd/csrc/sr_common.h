@@ -8,6 +8,7 @@
 #include "../../include/sr_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
