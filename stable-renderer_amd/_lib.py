@@ -21,7 +21,7 @@ class IgemmArgs(C.Structure):
                 ("zero_page", vp), ("B", i32), ("H", i32), ("W", i32), ("C1", i32), ("C2", i32), ("N", i32),
                 ("KH", i32), ("stride", i32), ("upsample", i32), ("act", i32), ("transpose_out", i32), ("ldt", i32),
                 ("out_f32", i32), ("dtype", i32), ("scale", f32), ("rowvec_ld", i32), ("workspace", vp),
-                ("workspace_bytes", C.c_int64)]
+                ("workspace_bytes", C.c_int64), ("tile", i32), ("split", i32)]
 
 
 class GroupNormArgs(C.Structure):

@@ -460,7 +460,23 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int n128 = (a.N + 127) / 128, n64 = (a.N + 63) / 64;
   const int64_t wg_128x128 = (int64_t)((M + 127) / 128) * n128;
   const bool waste128 = (n128 * 128 - a.N) * 8 > a.N;          // >12.5% padded columns with BN=128
-  const char* fenv = getenv("SR_IGEMM_TILE"); const int force = fenv ? atoi(fenv) : 0;   // tuning aid: 1=256x128x3, 2=128x128, 3=128x64, 4=64x64
+  const char* fenv = getenv("SR_IGEMM_TILE");                 // tuning aid, overrides args.tile
+  const int force = fenv ? atoi(fenv) : a.tile;              // 1=256x128x3, 2=128x128, 3=128x64, 4=64x64, 5=256x320
+  static const bool split_off = getenv("SR_SPLITK") && atoi(getenv("SR_SPLITK")) == 0;      // tuning / A-B aid
+  const int KT = a.KH * a.KH * ((a.C1 + a.C2) / (int)(128 / sizeof(T)));
+  const bool may_split = !TRANS && !split_off && a.split == 0 && a.workspace && a.act != 2 && a.N % 4 == 0 && KT >= 32;
+  if constexpr (!TRANS) {
+    if (may_split && (force == 2 || force == 3)) {           // tuned tile + modelled tail split
+      int tile0 = 0;
+      if (force == 2) {
+        const int S = plan_split(wg_128x128, KT, 512, 1.2, 128 * 128 * 4, a.workspace_bytes, &tile0);
+        if (S > 1) return launch_split<T, 128, 128>(a, M, Ho, Wo, tile0, S, st);
+      } else {
+        const int S = plan_split((int64_t)((M + 127) / 128) * n64, KT, 768, 0.93, 128 * 64 * 4, a.workspace_bytes, &tile0);
+        if (S > 1) return launch_split<T, 128, 64>(a, M, Ho, Wo, tile0, S, st);
+      }
+    }
+  }
   if (force == 2) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 3) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 4) return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
@@ -469,8 +485,11 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // activation tile is fetched once for N = 320, and 142 FLOP per byte staged through the 64 B/clk TCP->LDS path (a
     // 128x128 tile: 64 FLOP/B = exactly the MFMA rate, so that path saturates first).  Needs a full round of workgroups:
     // measured 830 vs 627 TF/s on the 64x64 C320 3x3 conv, 1086 vs 1000 on C1280, but 556 vs 678 at 32x32 C640.
+    if (force == 5 && a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 5 (256x320) needs N %% 320 == 0, N=%d", a.N);
     if (force == 5 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) >= 256))
       return launch<T, 256, 320, 4, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  } else {
+    if (force == 5) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 5 (256x320) is fp16, non-transposed only");
   }
   const int64_t wg_256x128 = (int64_t)((M + 255) / 256) * n128;
   const bool big = !waste128 && wg_256x128 >= 512;
@@ -478,9 +497,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   // 8x8 / 16x16 UNet levels).  fp32 partials go through the caller's workspace; a fixed-order reduce kernel applies the
   // epilogue (bit-reproducible, no float atomics).
   if constexpr (!TRANS) {
-    const int KT = a.KH * a.KH * ((a.C1 + a.C2) / (int)(128 / sizeof(T)));
-    static const bool off = getenv("SR_SPLITK") && atoi(getenv("SR_SPLITK")) == 0;      // tuning / A-B aid
-    if (force == 0 && !off && !big && a.workspace && a.act != 2 && a.N % 4 == 0 && KT >= 32) {
+    if (force == 0 && may_split && !big) {
       int tile0 = 0;
       if (!waste128) {
         const int S = plan_split(wg_128x128, KT, 512, 1.2, 128 * 128 * 4, a.workspace_bytes, &tile0);
@@ -496,7 +513,9 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   if (force == 1 || (force == 0 && big))
     return launch<T, 256, 128, 4, 2, 3, TRANS>(a, M, Ho, Wo, st);
   // (a 128x160 tile for N = 320 measured slower than five 64-wide tiles on MI355X: 487 vs 612 TF/s on the 3x3 conv)
-  if (!waste128 && wg_128x128 >= 192) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  // (1x1 layers with few 128x128 tiles run faster on 128x64: three co-resident workgroups per CU hide the short K loop's
+  //  ramp; 26.8 vs 31.3 us at M4096 K1280 N1280, 30.8 vs 36.0 at M16384 K640 N640 -- what the per-shape tuner picks too)
+  if (!waste128 && wg_128x128 >= 192 && !(a.KH == 1 && wg_128x128 <= 768)) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   const int64_t wg_128x64 = (int64_t)((M + 127) / 128) * n64;
   if (wg_128x64 >= 192) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
@@ -515,6 +534,7 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->upsample && a->stride != 1) SR_FAIL(SR_ERR_INVALID, "sr_igemm: upsample with stride");
   if (a->N <= 0 || a->B <= 0 || a->H <= 0 || a->W <= 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad sizes");
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
+  if (a->tile < 0 || a->tile > 5 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }
   else if (a->stride == 2) { Ho = (a->H + 2 * (a->KH / 2) - a->KH) / 2 + 1; Wo = (a->W + 2 * (a->KH / 2) - a->KH) / 2 + 1; }

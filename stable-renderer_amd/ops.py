@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (plumbing only: pointers, shapes, streams).  Every function
 launches HIP kernels from libsr_hip.so; nothing here computes on the CPU or through torch ops."""
 import ctypes as C
+import os
 
 import torch
 
@@ -87,6 +88,58 @@ def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C
 def igemm(*a, **k):
     ar = igemm_args(*a, **k)
     L.check(L.lib().sr_igemm(C.byref(ar), stream_ptr()))
+
+
+# ---- per-shape tile tuner ------------------------------------------------------------------------------------------------
+# The library's tile heuristic is a model of wave quantisation; the plan builder can instead MEASURE every legal tile /
+# split-K combination once per distinct layer shape (a plan is built once and replayed thousands of times) and pin the
+# winner in sr_igemm_args.tile/.split.  SR_AUTOTUNE=0 keeps the heuristic.
+_TUNED = {}
+_CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (3, 0), (3, -1), (4, -1), (5, -1))
+
+
+def autotune_enabled():
+    return os.environ.get("SR_AUTOTUNE", "1") != "0" and torch.cuda.is_available()
+
+
+def tune_igemm(ar, min_flops=1.0e9, reps=4):
+    """times the candidate (tile, split) settings of one op on the current stream and leaves the fastest in ``ar``"""
+    Ho, Wo = (2 * ar.H, 2 * ar.W) if ar.upsample else ((ar.H + ar.stride - 1) // ar.stride, (ar.W + ar.stride - 1) // ar.stride)
+    flops = 2.0 * ar.B * Ho * Wo * ar.N * ar.KH * ar.KH * (ar.C1 + ar.C2)
+    if flops < min_flops:
+        return
+    sig = (ar.dtype, ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample, ar.act, ar.transpose_out, ar.out_f32,
+           bool(ar.residual), bool(ar.rowvec))
+    if sig not in _TUNED:
+        lib, st = L.lib(), stream_ptr()
+        times = {}
+        for rnd in range(2):                                 # two interleaved rounds, min per candidate (clock ramp, noise)
+            for tile, split in _CANDIDATES:
+                if (ar.act == 2 or ar.transpose_out) and split == 0 and tile != 0:
+                    continue                                 # these never split: (tile, 0) == (tile, -1)
+                if rnd == 1 and (tile, split) not in times:
+                    continue
+                ar.tile, ar.split = tile, split
+                if lib.sr_igemm(C.byref(ar), st) != 0:       # illegal tile for this shape (also the warm-up launch)
+                    continue
+                n = reps if rnd == 0 else max(reps, min(40, int(1.0 / max(times[(tile, split)], 1e-3))))   # ~1 ms per candidate
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    lib.sr_igemm(C.byref(ar), st)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1) / n
+                times[(tile, split)] = min(t, times.get((tile, split), t)) if rnd == 1 else t
+        best, best_t = (0, 0), None
+        for c in _CANDIDATES:                                # 3 % hysteresis towards the earlier (heuristic-first) entry
+            if c in times and (best_t is None or times[c] < best_t * 0.97):
+                best, best_t = c, times[c]
+        _TUNED[sig] = best
+        if os.environ.get("SR_AUTOTUNE_LOG"):
+            print(f"[tune] B{ar.B} {ar.H}x{ar.W} C{ar.C1}+{ar.C2} N{ar.N} k{ar.KH} s{ar.stride} u{ar.upsample} act{ar.act} "
+                  f"t{ar.transpose_out} -> tile {best[0]} split {best[1]}  {best_t * 1e3:.1f} us", flush=True)
+    ar.tile, ar.split = _TUNED[sig]
 
 
 def groupnorm_args(x, gamma, beta, y, B, HW, C1, partials, x2=None, C2=0, groups=32, eps=1e-5, silu=False):

@@ -73,7 +73,10 @@ class PlanBuilder:
     # ---- ops ------------------------------------------------------------------------------------------
     def igemm(self, a, w, out, B, H, W, C1, N, **kw):
         self.hold(a, w, out, kw.get("a2"), kw.get("bias"), kw.get("rowvec"), kw.get("residual"))
-        self._emit(L.OP_IGEMM, "igemm", O.igemm_args(a, w, out, B, H, W, C1, N, dtype=self.dtype, **kw))
+        ar = O.igemm_args(a, w, out, B, H, W, C1, N, dtype=self.dtype, **kw)
+        if O.autotune_enabled():
+            O.tune_igemm(ar)
+        self._emit(L.OP_IGEMM, "igemm", ar)
         KH, st, up = kw.get("KH", 1), kw.get("stride", 1), kw.get("upsample", 0)
         Ho, Wo = (2 * H, 2 * W) if up else ((H + st - 1) // st, (W + st - 1) // st)
         f = 2 * B * Ho * Wo * N * KH * KH * (C1 + kw.get("C2", 0))
