@@ -558,9 +558,104 @@ def sec_dump():
     save("corrmap_dump_io", values_in=m._values, writtens_in=m._writtens, values_back=m2._values, writtens_back=m2._writtens)
 
 
+def sec_gbufdump():
+    """G-buffer dump layout (DiffusionManager._outputMap/_outputNumpyData/_outputDepthMap, diffusionManager.py:160-259).
+    The manager module cannot be imported here (its package pulls the GL managers), so the three methods are taken from the
+    reference FILE at generation time (ast -> exec with numpy/PIL) and run on seeded planes; the PNG/NPY files they write
+    are read back and stored as arrays (tests/golden/gbuffer_dump.npz)."""
+    import ast
+    import queue
+    import shutil
+    import tempfile
+    from PIL import Image
+    src = open(os.path.join(R.REF, "source/engine/managers/diffusionManager.py")).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DiffusionManager")
+    want = {"_outputNumpyData", "_outputMap", "_outputDepthMap"}
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert len(fns) == 3
+
+    class _Log:
+        @staticmethod
+        def error(msg):
+            raise RuntimeError(msg)
+    ns = dict(np=np, os=os, Image=Image, Optional=__import__("typing").Optional, EngineLogger=_Log)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "diffusionManager.py[methods]", "exec"), ns)
+    tmp = tempfile.mkdtemp()
+
+    class Fake:
+        _outputPath = tmp
+        _unfinished_queue = queue.Queue()
+    fake = Fake()
+    H, W = 24, 20
+    g = np.random.default_rng(11)
+    color = g.random((H, W, 4), dtype=np.float32)
+    color[..., 3] = (g.random((H, W)) > 0.3).astype(np.float32)
+    normal = g.random((H, W, 3), dtype=np.float32)
+    canny = (g.random((H, W, 3)) > 0.8).astype(np.float32)
+    ids = g.integers(0, 500, (H, W, 4)).astype(np.int32)
+    pos = g.standard_normal((H, W, 3)).astype(np.float32)
+    noise = g.standard_normal((H, W, 4)).astype(np.float16)
+    depth = g.random((H, W), dtype=np.float32) * (g.random((H, W)) > 0.4)
+    gray = g.random((H, W), dtype=np.float32)                 # 2-D map path of _outputMap
+    frame = 7
+    ns["_outputMap"](fake, "Color", color, True, np.uint8, frame)
+    ns["_outputMap"](fake, "normal", normal, True, np.uint8, frame)
+    ns["_outputMap"](fake, "canny", canny, True, np.uint8, frame)
+    ns["_outputMap"](fake, "gray", gray, True, np.uint8, None)
+    ns["_outputNumpyData"](fake, "id", ids, frame)
+    ns["_outputNumpyData"](fake, "pos", pos, frame)
+    ns["_outputNumpyData"](fake, "noise", noise, frame)
+    ns["_outputDepthMap"](fake, depth, frame)
+    back = {}
+    for name in ("color", "normal", "canny"):
+        back[name + "_png"] = np.asarray(Image.open(os.path.join(tmp, name, f"{name}_{frame}.png")))
+    back["gray_png"] = np.asarray(Image.open(os.path.join(tmp, "gray", "gray.png")))
+    back["depth_png"] = np.asarray(Image.open(os.path.join(tmp, "depth", f"depth_{frame}.png")))
+    for name in ("id", "pos", "noise"):
+        back[name + "_npy"] = np.load(os.path.join(tmp, name, f"{name}_{frame}.npy"))
+    shutil.rmtree(tmp)
+    # NoiseSequenceLoader.__call__ (_nodes/loaders.py:79-152) on two seeded 512^2 fp16 noise dumps (inputs are re-made from
+    # the seeds in the test; only the loader's output is stored)
+    lsrc = open(os.path.join(R.REF, "source/comfyUI/stable_rendering/_nodes/loaders.py")).read()
+    ltree = ast.parse(lsrc)
+    lcls = next(n for n in ltree.body if isinstance(n, ast.ClassDef) and n.name == "NoiseSequenceLoader")
+    call = next(n for n in lcls.body if isinstance(n, ast.FunctionDef) and n.name == "__call__")
+    call.args.defaults = []
+    for a in call.args.args:                                                   # drop the node-type annotations
+        a.annotation = None
+    call.returns = None
+    ast.fix_missing_locations(call)
+    mu = R.import_math_utils() if hasattr(R, "import_math_utils") else __import__("common_utils.math_utils", fromlist=["x"])
+    import re as _re
+
+    def extract_index(name, default):
+        m = _re.findall(r"\d+", os.path.splitext(name)[0])
+        return int(m[-1]) if m else default
+
+    class _L:
+        @staticmethod
+        def debug(*a, **k):
+            pass
+    lns = dict(os=os, np=np, torch=torch, extract_index=extract_index, ComfyUILogger=_L,
+               adaptive_instance_normalization=mu.adaptive_instance_normalization,
+               LATENT=lambda **kw: dict(kw))
+    exec(compile(ast.Module(body=[call], type_ignores=[]), "loaders.py[NoiseSequenceLoader.__call__]", "exec"), lns)
+    tmp2 = tempfile.mkdtemp()
+    for i, seed in enumerate((21, 22)):
+        np.save(os.path.join(tmp2, f"noise_{i}.npy"), np.random.default_rng(seed).standard_normal((512, 512, 4)).astype(np.float16))
+    with one_thread():
+        lat = lns["__call__"](None, tmp2, 0, 2, "SD15")
+    shutil.rmtree(tmp2)
+    back["loader_noise"] = lat["noise"].float().numpy()
+    back["loader_seeds"] = np.array([21, 22])
+    save("gbuffer_dump", color=color, normal=normal, canny=canny, ids=ids, pos=pos, noise=noise, depth=depth, gray=gray,
+         frame=np.int64(frame), **back)
+
 
 SECTIONS = dict(math=sec_math, idmap=sec_idmap, overlap=sec_overlap, corrmap=sec_corrmap, noisepool=sec_noisepool,
-                sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet, legacy=sec_legacy)
+                sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet, legacy=sec_legacy,
+                gbufdump=sec_gbufdump)
 
 if __name__ == "__main__":
     todo = _ARGV or list(SECTIONS)

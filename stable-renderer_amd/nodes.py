@@ -2,12 +2,14 @@
 ``__call__`` signatures (comfyUI/stable_rendering/_nodes/{data,samplers}.py, comfyUI/nodes.py VAEDecode/custom_ksampler),
 executing on the HIP path.  The node *registration* machinery (AdvancedNodeBase -> ComfyUI web UI, node_base.py:179-686) is
 UI plumbing and out of scope; a graph executor only needs these callables."""
+import os
 from functools import partial
 from typing import Callable, Optional, Tuple
 
+import numpy as np
 import torch
 
-from .corrmap import CorrespondMap
+from .corrmap import CorrespondMap, IDMap
 from .corresponder import DefaultCorresponder as _DefaultCorresponder
 from .corresponder import OverlapCorresponder as _OverlapCorresponder
 from .sampling import DiffusionRunner
@@ -52,6 +54,96 @@ class VirtualEngineDataNode(StableRenderingNode):
         return EngineData(frame_indices=list(range(n)), color_maps=color_maps, id_maps=id_maps, pos_maps=pos_maps,
                           normal_maps=normal_maps, depth_maps=depth_maps, canny_maps=canny_maps, noise_maps=noise_maps,
                           masks=masks, correspond_maps=correspond_maps, sprite_infos=sprites, env_prompts=env_prompt)
+
+
+def _extract_index(name, default):
+    """common_utils/path_utils.py extract_index: the last number in the file name"""
+    import re
+    m = re.findall(r"\d+", os.path.splitext(name)[0])
+    return int(m[-1]) if m else default
+
+
+def _sorted_files(directory, exts):
+    names = [f for f in os.listdir(directory) if f.endswith(exts) and os.path.exists(os.path.join(directory, f))]
+    return sorted(names, key=lambda n: _extract_index(n, names.index(n)))
+
+
+def _check_loader_args(directory, frame_start, num_frames, sd_version):
+    if not os.path.exists(directory):
+        raise FileNotFoundError(f"Directory {directory} not found")
+    if frame_start < 0:
+        raise ValueError("frame_start takes value larger than or equal to 0, got ", frame_start)
+    if num_frames <= 0:
+        raise ValueError("num_frames takes value larger 0, got ", frame_start)
+    if sd_version not in ["SD15", "SDXL"]:
+        raise ValueError("sd_version should be either SD15 or SDXL")
+
+
+class IDSequenceLoader(StableRenderingNode):
+    """_nodes/loaders.py:312-326"""
+    Category = "loader"
+
+    def __call__(self, directory, frame_start: int = 0, num_frames: int = 16, device="cuda") -> IDMap:
+        return IDMap.from_directory(directory=directory, frame_start=frame_start, num_frames=num_frames,
+                                    use_frame_indices_from_filename=False, device=device)
+
+
+class ImageSequenceLoader(StableRenderingNode):
+    """_nodes/loaders.py:19-76: RGB images of a dump directory, nearest-resized to the SD size, (N,H,W,3) in [0,1]"""
+    Category = "loader"
+
+    def __call__(self, directory, frame_start: int = 0, num_frames: int = 16, sd_version="SD15", device="cuda"):
+        from PIL import Image
+        _check_loader_args(directory, frame_start, num_frames, sd_version)
+        size = (512, 512) if sd_version == "SD15" else (1024, 1024)
+        out = []
+        for fn in _sorted_files(directory, (".jpeg", ".png", ".bmp", ".jpg"))[frame_start: frame_start + num_frames]:
+            a = torch.from_numpy(np.array(Image.open(os.path.join(directory, fn)).convert("RGB"))).permute(2, 0, 1)[None]
+            a = torch.nn.functional.interpolate(a, size=size)                   # nearest on uint8, as the reference
+            out.append(a.permute(0, 2, 3, 1) / 255.0)
+        return torch.cat(out, 0).to(device) if out else None
+
+
+class NoiseSequenceLoader(StableRenderingNode):
+    """_nodes/loaders.py:79-152: dumped engine noise (N,H,W,4) -> LATENT(noise = AdaIN(strip-pooled noise, full noise)).
+    The pooling is the same 64-consecutive-pixel row strip as RenderManager._save_frame_data and runs in ``sr_noise_pool``
+    (mask 0); the strip mean is kept in fp32 where the reference rounds it to the dump's fp16 before AdaIN."""
+    Category = "loader"
+
+    def __call__(self, directory, frame_start: int = 0, num_frames: int = 16, sd_version="SD15", device="cuda") -> LATENT:
+        from . import ops as O
+        _check_loader_args(directory, frame_start, num_frames, sd_version)
+        ts = []
+        for fn in _sorted_files(directory, (".jpeg", ".png", ".bmp", ".jpg", ".npy"))[frame_start: frame_start + num_frames]:
+            path = os.path.join(directory, fn)
+            if path.endswith(".npy"):
+                t = torch.from_numpy(np.load(path)).squeeze()
+                if t.dim() != 3:
+                    raise ValueError(f"Invalid shape of noise tensor: {t.shape}.")
+                if not (t.shape[-1] == 4 or t.shape[1] == 4):
+                    raise ValueError(f"Invalid noise tensor shape: {t.shape}.")
+            else:
+                from PIL import Image
+                t = torch.from_numpy(np.array(Image.open(path).convert("RGBA"))).permute(2, 0, 1) / 255.0
+            ts.append(t)
+        if not ts:
+            return None
+        if any(t.shape != ts[0].shape for t in ts):
+            raise ValueError("Tensor data has inconsistent shapes.")
+        noise = torch.stack(ts, 0)
+        _, height, width, channel = noise.shape
+        assert channel == 4, "Noise shape should be in BHW4"
+        unit = 64 if sd_version == "SD15" else 128
+        if height % unit != 0 or width % unit != 0:
+            raise ValueError(f"Noise shape for {sd_version} should be divisible by {unit}")
+        if height // unit != 8:
+            raise NotImplementedError("sr_noise_pool pools 64-pixel strips (512^2 SD1.5 / 1024^2 SDXL dumps)")
+        nz = noise.to(device=device, dtype=torch.float16).contiguous()
+        zeros = torch.zeros(1, height, width, dtype=torch.float16, device=device)          # mask 0: the noise itself
+        bg = torch.zeros(1, height, width, 4, dtype=torch.float32, device=device)
+        outs = [O.noise_pool(nz[i:i + 1], 1.0 - zeros, bg)[1] for i in range(nz.shape[0])]
+        lat = torch.cat(outs, 0)
+        return LATENT(samples=torch.zeros_like(lat), noise=lat)
 
 
 class EmptyCorrMaps(StableRenderingNode):

@@ -58,3 +58,34 @@ def test_raster_only_engine_matches_oracle_ids():
                  noise_tex=None if t.noise_tex is None else t.noise_tex.cpu().numpy().view(np.uint16),
                  diffuse_tex=None if t.diffuse_tex is None else t.diffuse_tex.cpu().float().numpy())
     assert np.array_equal(ed.id_maps.tensor[8].cpu().numpy(), ref.id)
+
+
+def test_sequence_loaders_read_a_dump(tmp_path):
+    """IDSequenceLoader / NoiseSequenceLoader / ImageSequenceLoader (_nodes/loaders.py) on a dump directory written by
+    dumps.GBufferDump; the noise latent is compared with the reference loader's output (golden, fp16-resolution tolerance:
+    the reference rounds the strip mean to fp16 before AdaIN, sr_noise_pool keeps fp32)."""
+    import numpy as np
+    from stable_renderer_amd.dumps import GBufferDump
+    from stable_renderer_amd import nodes as N
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gbuffer_dump.npz"))
+    d = GBufferDump(str(tmp_path))
+    for i, seed in enumerate(g["loader_seeds"].tolist()):
+        d.output_numpy("noise", np.random.default_rng(seed).standard_normal((512, 512, 4)).astype(np.float16), i)
+        ids = np.zeros((512, 512, 4), np.int16)
+        ids[..., 3] = i + 1
+        d.output_numpy("id", ids, i)
+        d.output_map("color", np.full((512, 512, 3), 0.25 * (i + 1), np.float32), frame_num=i)
+    lat = N.NoiseSequenceLoader()(str(tmp_path / "noise"), 0, 2, "SD15")
+    ref = torch.from_numpy(g["loader_noise"])
+    got = lat["noise"].float().cpu()
+    assert got.shape == ref.shape == (2, 4, 64, 64)
+    assert float((got - ref).abs().max()) < 4e-3 * float(ref.abs().max()), float((got - ref).abs().max())
+    assert float(lat["samples"].abs().max()) == 0.0
+    idm = N.IDSequenceLoader()(str(tmp_path / "id"), 0, 2)
+    assert idm.tensor.shape == (2, 512, 512, 4) and idm.frame_indices == [0, 1]
+    assert int(idm.tensor[1, 0, 0, 3]) == 2
+    img = N.ImageSequenceLoader()(str(tmp_path / "color"), 0, 2, "SD15")
+    assert img.shape == (2, 512, 512, 3)
+    assert abs(float(img[1, 5, 5, 0]) - int(0.5 * 255) / 255.0) < 1e-6
+    with pytest.raises(FileNotFoundError):
+        N.NoiseSequenceLoader()(str(tmp_path / "nope"))

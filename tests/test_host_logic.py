@@ -84,3 +84,30 @@ def test_scene_math():
     assert sp.tris.max() < 1089 and (sp.tris % 33 != 32).all()          # seam column never referenced (mesh.py:555-558)
     t = S.strip_to_triangles([0, 1, 2, 3])
     assert t.tolist() == [[0, 1, 2], [2, 1, 3]]
+
+
+def test_gbuffer_dump_layout_matches_reference(tmp_path):
+    """dumps.GBufferDump writes what DiffusionManager._outputMap/_outputNumpyData/_outputDepthMap write
+    (diffusionManager.py:160-259; golden produced by those reference methods, oracle/gen_golden.py gbufdump)."""
+    import numpy as np
+    from PIL import Image
+    from stable_renderer_amd.dumps import GBufferDump
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gbuffer_dump.npz"))
+    d = GBufferDump(str(tmp_path))
+    f = int(g["frame"])
+    d.output_map("Color", g["color"], frame_num=f)
+    d.output_map("normal", g["normal"], frame_num=f)
+    d.output_map("canny", g["canny"], frame_num=f)
+    d.output_map("gray", g["gray"])
+    d.output_numpy("id", g["ids"], f)
+    d.output_numpy("pos", g["pos"], f)
+    d.output_numpy("noise", g["noise"], f)
+    d.output_depth(g["depth"], f)
+    for name in ("color", "normal", "canny"):
+        got = np.asarray(Image.open(tmp_path / name / f"{name}_{f}.png"))
+        assert got.shape == g[name + "_png"].shape and (got == g[name + "_png"]).all(), name
+    assert (np.asarray(Image.open(tmp_path / "gray" / "gray.png")) == g["gray_png"]).all()
+    assert (np.asarray(Image.open(tmp_path / "depth" / f"depth_{f}.png")) == g["depth_png"]).all()
+    for name in ("id", "pos", "noise"):
+        got = np.load(tmp_path / name / f"{name}_{f}.npy")
+        assert got.dtype == g[name + "_npy"].dtype and (got == g[name + "_npy"]).all(), name
