@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print per-stage wall times of one extra (synchronised) call to stderr")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="build the pipeline, run ONE call, then only the igemm-subset replays of the roofline object (the command "
+                         "profiled with rocprofv3 for profiles/: its kernel stats then cover exactly those launches)")
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"],
                     help="replica: every GPU bakes its own 8-view group (weak scaling, no collective); shard: ONE 8-view group "
                          "split over the GPUs with the latent all-gather / K,V-source broadcast over RCCL (strong scaling)")
@@ -89,6 +92,9 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+    if a.roofline_only:                                       # no calls: just the UNet step plan (as a sampling run builds it)
+        a.warmup, a.steps, a.no_cpu_baseline = 0, 0, True
+        pipe.runner._load_ctx(pipe.runner._ensure_plan([3]))
     for _ in range(a.warmup):
         pipe.call()
     sync()
@@ -96,7 +102,7 @@ def main():
     for _ in range(a.steps):
         pipe.call()
     sync()
-    dt = time.perf_counter() - t0
+    dt = max(time.perf_counter() - t0, 1e-9)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -143,7 +149,7 @@ def main():
         cpu = cpu_baseline()
     if rank == 0:
         out = {"metric": "frames/sec @512^2, SD1.5 20-step img2img, 8-view overlap", "value": round(frames / dt, 4), "unit": "frames/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 2),
                "higher_is_better": True, "scaling": "strong" if shard is not None else "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "bake_ball.py sphere scene 512x512 (HIP raster, corr-map proxy k=6, texcoord ids) -> SD1.5-shaped UNet "
                                       "(859.5M params, random init) %d denoise steps ddim/normal cfg 8, %d views per call with "

@@ -95,6 +95,11 @@ def igemm(*a, **k):
 # split-K combination once per distinct layer shape (a plan is built once and replayed thousands of times) and pin the
 # winner in sr_igemm_args.tile/.split.  SR_AUTOTUNE=0 keeps the heuristic.
 _TUNED = {}
+_TUNE_CACHE = os.environ.get("SR_AUTOTUNE_CACHE")            # optional JSON file: load the table if present, save after tuning
+if _TUNE_CACHE and os.path.exists(_TUNE_CACHE):
+    import json as _json
+    with open(_TUNE_CACHE) as _f:
+        _TUNED.update({tuple(_json.loads(k)): tuple(v) for k, v in _json.load(_f).items()})
 _CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (3, 0), (3, -1), (4, -1), (5, -1))
 
 
@@ -136,6 +141,10 @@ def tune_igemm(ar, min_flops=1.0e9, reps=4):
             if c in times and (best_t is None or times[c] < best_t * 0.97):
                 best, best_t = c, times[c]
         _TUNED[sig] = best
+        if _TUNE_CACHE:
+            import json as _json
+            with open(_TUNE_CACHE, "w") as _f:
+                _json.dump({_json.dumps([int(x) for x in k]): list(v) for k, v in _TUNED.items()}, _f)
         if os.environ.get("SR_AUTOTUNE_LOG"):
             print(f"[tune] B{ar.B} {ar.H}x{ar.W} C{ar.C1}+{ar.C2} N{ar.N} k{ar.KH} s{ar.stride} u{ar.upsample} act{ar.act} "
                   f"t{ar.transpose_out} -> tile {best[0]} split {best[1]}  {best_t * 1e3:.1f} us", flush=True)
