@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
 // S lives in two register sets that swap roles every tile (loop unrolled by two); K/V tiles go through a 3-slot LDS ring
 // (tile t+2 is written while t and t+1 are read) with ONE barrier per tile; global loads run one more tile ahead in
 // registers.  The interleave itself is requested with sched_group_barrier (1 MFMA : n VALU).
-template <int DQ, int DT, bool SR>
-__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const sr_attention_args p) {
+template <int DQ, int DT, bool SR, int MB>
+__global__ __launch_bounds__(256, MB) void attn_pipe_kernel(const sr_attention_args p) {
   using T = _Float16;
   constexpr int EPC = 8, QT = 2;
   constexpr int NCH = 4 * DQ, KROW = NCH * 16, VROW = KV_TILE * 2 + 8, VCH = KV_TILE * 2 / 16;
@@ -527,11 +527,11 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const sr_attention_ar
   }
 }
 
-template <int DQ, int DT, bool SR>
+template <int DQ, int DT, bool SR, int MB = 2>
 int launch_pipe(const sr_attention_args& a, hipStream_t st) {
   dim3 grid(sr_cdiv(a.Tq, 128), a.heads, a.B);
   constexpr int lds = 3 * (KV_TILE * 4 * DQ * 16 + DT * 16 * (KV_TILE * 2 + 8));
-  auto k = attn_pipe_kernel<DQ, DT, SR>;
+  auto k = attn_pipe_kernel<DQ, DT, SR, MB>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
@@ -571,7 +571,11 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
     if (d <= 48) {
       // long key sequences (64x64 self-attention): the software-pipelined loop, 819 vs 895 us (Bk=1) / 722 vs 815 (Bk=B) at
       // B16 T4096 d40; short ones (the 77-token prompt) stay on the simple loop, whose prologue is cheaper
-      if (pipe && a->Tk >= 512) return (d & 15) ? launch_pipe<2, 3, true>(*a, st) : launch_pipe<2, 3, false>(*a, st);
+      if (pipe && a->Tk >= 512) {
+        static const int mb = getenv("SR_ATTN_MB") ? atoi(getenv("SR_ATTN_MB")) : 2;      // tuning aid
+        if (mb == 3 && (d & 15)) return launch_pipe<2, 3, true, 3>(*a, st);
+        return (d & 15) ? launch_pipe<2, 3, true>(*a, st) : launch_pipe<2, 3, false>(*a, st);
+      }
       return (d & 15) ? launch<_Float16, 2, 3, 2, true>(*a, st) : launch<_Float16, 2, 3, 2>(*a, st);
     }
     if (d <= 64) return launch<_Float16, 2, 4, 2>(*a, st);

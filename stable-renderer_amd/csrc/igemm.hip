@@ -18,25 +18,39 @@
 
 namespace {
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false>
+// BKB = bytes of K per LDS stage: 128 (two MFMA k-substeps, 8 rows x 8 chunks per LDS-DMA instruction) or 64 (one k-substep,
+// 16 rows x 4 chunks) -- the 64-byte form halves a stage so that the 256x320 tile gets a FOUR-deep ring in 144 KB (three
+// K-steps of loads in flight instead of one: that tile is otherwise bound by the exposed load latency of every K-step).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
                                                                         const int NT, const int nwg, const int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KE = 128 / (int)sizeof(T);            // elements of K per step
+  constexpr int KE = BKB / (int)sizeof(T);            // elements of K per step
   constexpr int NW = WAVES_M * WAVES_N;               // waves per workgroup (4 or 8)
-  constexpr int NIP = BM / 8 / NW, NIQ = BN / 8 / NW;  // glds instructions per wave per K-step (X, W tiles)
+  constexpr int RPI = 1024 / BKB;                     // tile rows one LDS-DMA wave instruction fills (1 KiB)
+  constexpr int GP = BM / RPI, GQ = BN / RPI;         // row groups of the X / W tiles
+  constexpr int NIP = (GP + NW - 1) / NW, NIQ = (GQ + NW - 1) / NW;   // glds instructions per wave per K-step; when the
+                                                      // groups do not split evenly the surplus instructions re-fetch the last group
   constexpr int TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int STAGE_BYTES = (BM + BN) * BKB;
+  constexpr int FBLK = 16 * BKB;                      // bytes of one 16-row fragment block
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
+  static_assert(BKB == 128 || BKB == 64, "K bytes per stage");
+  static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must be whole LDS-DMA groups");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = tile0 + sr_xcd_remap(blockIdx.x, nwg);      // this launch covers tiles [tile0, tile0 + nwg)
   const int mt = wg / NT, nt = wg - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int lrow = lane >> 3;
-  const int lchunk = (lane & 7) ^ lrow;                // logical 16-B chunk this lane fetches (source swizzle)
+  // LDS-DMA writes lane-linearly (row = lane / chunks-per-row, slot = lane % chunks-per-row), so the bank swizzle is applied to
+  // the SOURCE: the lane fetches the logical 16-B chunk whose swizzled slot it fills.  128-B rows: slot = chunk ^ (row & 7).
+  // 64-B rows (rows r and r+4 share banks): slot = ((row >> 2) & 3) ^ F[chunk], F = {0,3,1,2}, which makes every 16-lane
+  // group of ds_read_b128 ({0-3,12-15,20-27}, ...) hit 16 distinct (row & 3, slot) pairs = all 64 banks once.
+  const int lrow = BKB == 128 ? lane >> 3 : lane >> 2;
+  int lchunk;
+  if constexpr (BKB == 128) lchunk = (lane & 7) ^ lrow;
+  else { const int q = (lane & 3) ^ ((lrow >> 2) & 3); lchunk = (0x1320 >> (4 * q)) & 3; }   // F^-1 = {0,2,3,1}
 
   const int C1 = p.C1, C2 = p.C2, Ctot = C1 + C2;
   const int K1 = C1 / KE, KPT = Ctot / KE;             // K-steps from source a / per tap
@@ -49,7 +63,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   int pb[NIP], py[NIP], px[NIP];
 #pragma unroll
   for (int i = 0; i < NIP; ++i) {
-    const int m = m0 + (i * NW + wv) * 8 + lrow;
+    const int gi = (i * NW + wv) < GP ? (i * NW + wv) : GP - 1;
+    const int m = m0 + gi * RPI + lrow;
     if (m < M) {
       const int b = m / rpb, rem = m - b * rpb, oy = rem / Wo;
       pb[i] = b; py[i] = oy * p.stride - pad; px[i] = (rem - oy * Wo) * p.stride - pad;
@@ -75,7 +90,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   const char* wrow[NIQ];
 #pragma unroll
   for (int i = 0; i < NIQ; ++i) {
-    const int n = n0 + (i * NW + wv) * 8 + lrow;
+    const int gi = (i * NW + wv) < GQ ? (i * NW + wv) : GQ - 1;
+    const int n = n0 + gi * RPI + lrow;
     wrow[i] = (const char*)p.w + ((int64_t)n * KT * KE) * (int64_t)sizeof(T) + lchunk * 16;
   }
 
@@ -85,26 +101,28 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
     kt0 = (int)((int64_t)KT * blockIdx.y / gridDim.y);
     kt1 = (int)((int64_t)KT * (blockIdx.y + 1) / gridDim.y);
 #pragma unroll
-    for (int i = 0; i < NIQ; ++i) wrow[i] += (int64_t)kt0 * 128;
+    for (int i = 0; i < NIQ; ++i) wrow[i] += (int64_t)kt0 * BKB;
   }
   int s_tap = kt0 / KPT, s_kk = kt0 - s_tap * KPT;
   set_tap(s_tap);
   auto stage = [&](int buf) {                            // issue the async loads of the next K-step
     char* tP = smem + buf * STAGE_BYTES;
-    char* tQ = tP + BM * 128;
+    char* tQ = tP + BM * BKB;
     const bool fromA = s_kk < K1;
-    const int off = (fromA ? s_kk : s_kk - K1) * 128;
+    const int off = (fromA ? s_kk : s_kk - K1) * BKB;
+    auto gp = [&](int i) { return ((i * NW + wv) < GP ? (i * NW + wv) : GP - 1) * 1024; };   // LDS offset of the row group
+    auto gq = [&](int i) { return ((i * NW + wv) < GQ ? (i * NW + wv) : GQ - 1) * 1024; };
     if constexpr (STAGES == 2) {
 #pragma unroll
-      for (int i = 0; i < NIP; ++i) sr_glds16((fromA ? rowA[i] : rowB[i]) + off, tP + (i * NW + wv) * 1024);
+      for (int i = 0; i < NIP; ++i) sr_glds16((fromA ? rowA[i] : rowB[i]) + off, tP + gp(i));
 #pragma unroll
-      for (int i = 0; i < NIQ; ++i) { sr_glds16(wrow[i], tQ + (i * NW + wv) * 1024); wrow[i] += 128; }
+      for (int i = 0; i < NIQ; ++i) { sr_glds16(wrow[i], tQ + gq(i)); wrow[i] += BKB; }
     } else {
       const unsigned lP = __builtin_amdgcn_readfirstlane(sr_lds_addr(tP)), lQ = __builtin_amdgcn_readfirstlane(sr_lds_addr(tQ));
 #pragma unroll
-      for (int i = 0; i < NIP; ++i) sr_glds16_asm((fromA ? rowA[i] : rowB[i]) + off, lP + (i * NW + wv) * 1024);
+      for (int i = 0; i < NIP; ++i) sr_glds16_asm((fromA ? rowA[i] : rowB[i]) + off, lP + gp(i));
 #pragma unroll
-      for (int i = 0; i < NIQ; ++i) { sr_glds16_asm(wrow[i], lQ + (i * NW + wv) * 1024); wrow[i] += 128; }
+      for (int i = 0; i < NIQ; ++i) { sr_glds16_asm(wrow[i], lQ + gq(i)); wrow[i] += BKB; }
     }
     if (++s_kk == KPT) { s_kk = 0; if (++s_tap < ntaps) set_tap(s_tap); }
   };
@@ -114,8 +132,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   const int wm = wv / WAVES_N, wn = wv - wm * WAVES_N;
   const int pm0 = wm * (BM / WAVES_M), qn0 = wn * (BN / WAVES_N);
   int foff[2];
-  foff[0] = c16 * 128 + (((0 + g4) ^ (c16 & 7)) << 4);
-  foff[1] = c16 * 128 + (((4 + g4) ^ (c16 & 7)) << 4);
+  if constexpr (BKB == 128) {
+    foff[0] = c16 * 128 + (((0 + g4) ^ (c16 & 7)) << 4);
+    foff[1] = c16 * 128 + (((4 + g4) ^ (c16 & 7)) << 4);
+  } else {
+    foff[0] = foff[1] = c16 * 64 + ((((c16 >> 2) & 3) ^ ((0x2130 >> (4 * g4)) & 3)) << 4);        // F = {0,3,1,2}
+  }
 
   constexpr int TA = TRANS ? TM : TN, TB = TRANS ? TN : TM;
   f32x4 acc[TA][TB];
@@ -125,15 +147,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
     for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int buf) {
-    const char* tP = smem + buf * STAGE_BYTES + pm0 * 128;
-    const char* tQ = smem + buf * STAGE_BYTES + BM * 128 + qn0 * 128;
+    const char* tP = smem + buf * STAGE_BYTES + pm0 * BKB;
+    const char* tQ = smem + buf * STAGE_BYTES + BM * BKB + qn0 * BKB;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < BKB / 64; ++j) {
       uint4 xf[TM], wf[TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) xf[t] = *(const uint4*)(tP + t * 2048 + foff[j]);
+      for (int t = 0; t < TM; ++t) xf[t] = *(const uint4*)(tP + t * FBLK + foff[j]);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) wf[t] = *(const uint4*)(tQ + t * 2048 + foff[j]);
+      for (int t = 0; t < TN; ++t) wf[t] = *(const uint4*)(tQ + t * FBLK + foff[j]);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -152,21 +174,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
       compute(kt & 1);
     }
   } else {
-    // 3-deep LDS ring, loads run TWO K-steps ahead: wait only for the oldest stage (counted vmcnt, never 0 while a
-    // younger stage is in flight) and synchronise with a raw s_barrier so the in-flight LDS-DMA is not drained
-    constexpr int PER_STAGE = NIP + NIQ;                 // glds instructions one wave issues per stage
-    static_assert(PER_STAGE < 16, "vmcnt immediate");
-    stage(0);
-    if (KT > 1) stage(1);
+    // STAGES-deep LDS ring, loads run D = STAGES-1 K-steps ahead: wait only for the oldest stage (counted vmcnt, never 0
+    // while a younger stage is in flight) and synchronise with a raw s_barrier so the in-flight LDS-DMA is not drained
+    constexpr int PER_STAGE = NIP + NIQ;                 // glds instructions one wave issues per stage (same for every wave)
+    constexpr int D = STAGES - 1;
+    static_assert(STAGES == 3 || STAGES == 4, "ring depth");
+    static_assert(PER_STAGE * (D - 1) < 64, "vmcnt immediate");
+#pragma unroll
+    for (int i = 0; i < D; ++i) if (i < KT) stage(i);
     int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
-      // the asm-issued LDS-DMA is invisible to hipcc's wait-count pass, so these counted waits are the only ordering
-      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
-      else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the asm-issued LDS-DMA is invisible to hipcc's wait-count pass, so these counted waits are the only ordering:
+      // leave the min(D-1, remaining) younger stages in flight
+      const int younger = KT - 1 - kt;
+      if (younger >= D - 1)                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (D - 1)) : "memory");
+      else if (D == 3 && younger == 1)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
+      else                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // stage kt visible to all; everyone finished step kt-1
-      if (kt + 2 < KT) { int nb = cur + 2; if (nb >= 3) nb -= 3; stage(nb); }
+      if (kt + D < KT) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; stage(nb); }
       compute(cur);
-      if (++cur == 3) cur = 0;
+      if (++cur == STAGES) cur = 0;
     }
   }
 
@@ -351,18 +378,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128>
 int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int Npad = (a.N + 127) / 128 * 128;
   const int MT = (M + BM - 1) / BM, NT = Npad / BN;
   // skip all-padding n-tiles
   const int NTv = (a.N + BN - 1) / BN;
   const int nwg = MT * NTv;
-  constexpr int lds_stage = STAGES * (BM + BN) * 128;
+  constexpr int lds_stage = STAGES * (BM + BN) * BKB;
   constexpr int lds_epi_all = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);   // fp32 output sub-tiles of all waves
   constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
   constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS>;
+  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   (void)NT;
@@ -481,15 +508,18 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   if (force == 3) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 4) return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if constexpr (!TRANS && sizeof(T) == 2) {
+    // (4-wave 128x128 / 128x64 tiles with a 4-deep ring of 64-byte K-steps measured 5..30 % slower than their 2 x 128-byte
+    //  form on every UNet shape: twice the barriers per K, and those tiles already overlap through co-resident workgroups)
     // 256x320 tile (8 waves, 64x160 per wave): every UNet layer width is a multiple of 320, so no padded columns, the
     // activation tile is fetched once for N = 320, and 142 FLOP per byte staged through the 64 B/clk TCP->LDS path (a
     // 128x128 tile: 64 FLOP/B = exactly the MFMA rate, so that path saturates first).  Needs a full round of workgroups:
     // measured 830 vs 627 TF/s on the 64x64 C320 3x3 conv, 1086 vs 1000 on C1280, but 556 vs 678 at 32x32 C640.
-    if (force == 5 && a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 5 (256x320) needs N %% 320 == 0, N=%d", a.N);
+    if ((force == 5 || force == 6) && a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d (256x320) needs N %% 320 == 0, N=%d", force, a.N);
+    if (force == 6) return launch<T, 256, 320, 4, 2, 4, TRANS, 64>(a, M, Ho, Wo, st);
     if (force == 5 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) >= 256))
       return launch<T, 256, 320, 4, 2, 2, TRANS>(a, M, Ho, Wo, st);
   } else {
-    if (force == 5) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 5 (256x320) is fp16, non-transposed only");
+    if (force >= 5) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d is fp16, non-transposed only", force);
   }
   const int64_t wg_256x128 = (int64_t)((M + 255) / 256) * n128;
   const bool big = !waste128 && wg_256x128 >= 512;
@@ -534,7 +564,7 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->upsample && a->stride != 1) SR_FAIL(SR_ERR_INVALID, "sr_igemm: upsample with stride");
   if (a->N <= 0 || a->B <= 0 || a->H <= 0 || a->W <= 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad sizes");
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
-  if (a->tile < 0 || a->tile > 5 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
+  if (a->tile < 0 || a->tile > 6 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }
   else if (a->stride == 2) { Ho = (a->H + 2 * (a->KH / 2) - a->KH) / 2 + 1; Wo = (a->W + 2 * (a->KH / 2) - a->KH) / 2 + 1; }

@@ -71,7 +71,7 @@ def workspace(device, nbytes=64 << 20):
 
 
 def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C2=0, bias=None, rowvec=None,
-               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0):
+               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0, tile=0, split=0):
     ar = L.IgemmArgs()
     ar.a, ar.a2, ar.w, ar.bias, ar.rowvec, ar.residual, ar.out = _p(a), _p(a2), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
     ar.zero_page = _p(zero_page(a.device))
@@ -80,6 +80,7 @@ def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C
     ar.dtype = DT[a.dtype if dtype is None else dtype]
     ar.scale = scale
     ar.rowvec_ld = rowvec_ld
+    ar.tile, ar.split = tile, split
     ws = workspace(a.device)
     ar.workspace, ar.workspace_bytes = _p(ws), ws.numel()
     return ar
@@ -100,7 +101,7 @@ if _TUNE_CACHE and os.path.exists(_TUNE_CACHE):
     import json as _json
     with open(_TUNE_CACHE) as _f:
         _TUNED.update({tuple(_json.loads(k)): tuple(v) for k, v in _json.load(_f).items()})
-_CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (3, 0), (3, -1), (4, -1), (5, -1))
+_CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (3, 0), (3, -1), (4, -1), (5, -1), (6, -1))
 
 
 def autotune_enabled():

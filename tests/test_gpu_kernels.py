@@ -136,6 +136,42 @@ def test_igemm(ops, dtype, case):
     close(got, ref, dtype, scale=ref.abs().max().item())
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("act", [0, 2])
+def test_igemm_forced_tiles(ops, tile, act):
+    """every tile configuration the tuner may pin (sr_igemm_args.tile), incl. the 256x320 tiles with 2 x 128-byte and
+    4 x 64-byte LDS stages, on a 3x3 conv with concat source, bias, time-embedding slice and residual / GEGLU"""
+    dtype, dev = torch.float16, "cuda"
+    B, H, W, C1, C2, N, KH = 2, 24, 20, 128, 64, 640, 3
+    x = rnd(1, B, C1 + C2, H, W)
+    w = rnd(2, N, C1 + C2, KH, KH) * ((C1 + C2) * 9) ** -0.5
+    bias, rowvec = rnd(3, N) * 0.1, rnd(4, B, N)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), bias, padding=1) + rowvec[:, :, None, None]
+    nout = N
+    resid = None
+    if act == 2:
+        a, g = ref.chunk(2, dim=1)
+        ref = a * F.gelu(g)
+        nout = N // 2
+    else:
+        resid = rnd(5, B, N, H, W)
+        ref = ref + resid.to(dtype).float()
+    xa = x[:, :C1].permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    xb = x[:, C1:].permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    wp = ops.pack_conv_weight(w, dtype, geglu=(act == 2)).to(dev)
+    bp = ops.pack_bias(bias, geglu=(act == 2)).to(dev)
+    rvp = ops.pack_bias(rowvec.reshape(-1), geglu=False).reshape(B, N)
+    if act == 2:                                            # the row vector follows the interleaved (value, gate) order too
+        rvp = torch.stack([rowvec[:, :N // 2], rowvec[:, N // 2:]], dim=2).reshape(B, N).contiguous()
+    M = B * H * W
+    out = torch.zeros(M, nout, dtype=dtype, device=dev)
+    rs = resid.permute(0, 2, 3, 1).reshape(M, N).contiguous().to(dtype).to(dev) if resid is not None else None
+    ops.igemm(xa, wp, out, B, H, W, C1, N, KH=KH, a2=xb, C2=C2, bias=bp, rowvec=rvp.to(dev), residual=rs, act=act, tile=tile, split=-1)
+    torch.cuda.synchronize()
+    got = out.float().cpu().reshape(B, H, W, nout).permute(0, 3, 1, 2)
+    close(got, ref, dtype, scale=ref.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_out_f32_and_scale(ops, dtype):
     ke = ops.kelems(dtype)
