@@ -198,7 +198,8 @@ int sr_adain(const float* content, int64_t c_ps, int64_t c_cs, int64_t c_ns, int
 
 /* Engine noise -> latent noise (RenderManager._save_frame_data, engine/managers/renderManager.py:926-936):
  * n = noise*(1-mask) + bg*mask (fp16 product, fp32 sum), 64-pixel row-strip means ("view(-1,8,8,4)"),
- * then AdaIN against the full-res fp16 noise -> out (1,4,H/8,W/8) fp32.  pooled: (H/8*W/8, 4) fp32. */
+ * then AdaIN against the full-res fp16 noise -> out (1,4,H/8,W/8) fp32.  pooled: (H/8*W/8, 4) fp32.
+ * stats: optional scratch of 2048 floats -- with it the style statistics are reduced by 256 workgroups instead of 4. */
 int sr_noise_pool(const void* noise_f16, const void* alpha_f16, const float* bg, float* pooled, float* out,
                   int32_t H, int32_t W, float* stats, void* stream);
 

@@ -14,7 +14,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 EXTRA = {"raster.hip": ["-ffp-contract=off"],
          # softmax row maxima never see a NaN (masked scores are -inf, every tile has a valid key): drop the canonicalising
          # v_max x,x the compiler otherwise adds around every fmaxf in the VALU-bound loop
-         "attention.hip": ["-fno-honor-nans"]}
+         "attention.hip": ["-fno-honor-nans"],
+         # overlap_accum's float atomicAdd targets plain device memory (torch / hipMalloc allocations): let it be the native
+         # global_atomic_add_f32 instead of a compare-and-swap loop
+         "overlap.hip": ["-munsafe-fp-atomics"]}
 HEADERS = ["sr_common.h", os.path.join("..", "..", "include", "sr_hip.h")]
 
 
@@ -29,7 +32,7 @@ def _needs(src, obj):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
+    deps = [os.path.join(HERE, src), os.path.abspath(__file__)] + [os.path.join(HERE, h) for h in HEADERS]   # flags live in this file
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -119,19 +119,22 @@ __global__ __launch_bounds__(256) void overlap_apply(float* __restrict__ x, cons
 template <typename TS>
 __global__ __launch_bounds__(256) void adain_kernel(const float* __restrict__ content, int64_t c_ps, int64_t c_cs, int64_t c_ns, int HWc,
                                                     const TS* __restrict__ style, int64_t s_ps, int64_t s_cs, int64_t s_ns, int HWs,
-                                                    float* __restrict__ out, int C, float eps, int half_stats) {
+                                                    float* __restrict__ out, int C, float eps, int half_stats,
+                                                    const float* __restrict__ style_part = nullptr, int nblk = 0) {
   __shared__ float red[4];
   const int n = blockIdx.x / C, c = blockIdx.x - n * C;
   const float* cp = content + n * c_ns + c * c_cs;
   const TS* sp = style + n * s_ns + c * s_cs;
   float a = 0.f, b = 0.f;
   for (int p = threadIdx.x; p < HWc; p += 256) a += cp[p * c_ps];
-  for (int p = threadIdx.x; p < HWs; p += 256) b += sr_load_f(sp + p * s_ps);
+  if (style_part) { for (int i = threadIdx.x; i < nblk; i += 256) b += style_part[i * C + c]; }      // per-block sums (pass A)
+  else            { for (int p = threadIdx.x; p < HWs; p += 256) b += sr_load_f(sp + p * s_ps); }
   const float mc = block_sum(a, red) / (float)HWc;
   float ms = block_sum(b, red) / (float)HWs;
   a = 0.f; b = 0.f;
   for (int p = threadIdx.x; p < HWc; p += 256) { const float t = cp[p * c_ps] - mc; a += t * t; }
-  for (int p = threadIdx.x; p < HWs; p += 256) { const float t = sr_load_f(sp + p * s_ps) - ms; b += t * t; }
+  if (style_part) { for (int i = threadIdx.x; i < nblk; i += 256) b += style_part[(nblk + i) * C + c]; }   // centred squares (pass B)
+  else            { for (int p = threadIdx.x; p < HWs; p += 256) { const float t = sr_load_f(sp + p * s_ps) - ms; b += t * t; } }
   const float varc = block_sum(a, red) / (float)(HWc - 1) + eps;
   float vars = block_sum(b, red) / (float)(HWs - 1);
   float stds;
@@ -146,6 +149,34 @@ __global__ __launch_bounds__(256) void adain_kernel(const float* __restrict__ co
   const float stdc = sqrtf(varc);
   float* op = out + (int64_t)blockIdx.x * HWc;
   for (int p = threadIdx.x; p < HWc; p += 256) op[p] = (cp[p * c_ps] - mc) / stdc * stds + ms;
+}
+
+// Style statistics of an RGBA16F plane (HW pixels x 4 channels) spread over the chip instead of one workgroup per channel:
+// pass A writes per-block channel sums part[blk][4]; pass B re-reduces them (fixed order) to the means and writes the centred
+// sums of squares part[nblk + blk][4].  adain_kernel then only sums 2 x nblk partials per channel.
+__global__ __launch_bounds__(256) void style_partial_rgba16(const _Float16* __restrict__ style, int HW, float* __restrict__ part, int nblk,
+                                                            int pass) {
+  __shared__ float red[4];
+  __shared__ float mean[4];
+  if (pass == 1) {
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < nblk; i += 256)
+      for (int c = 0; c < 4; ++c) m[c] += part[i * 4 + c];
+    for (int c = 0; c < 4; ++c) { const float t = block_sum(m[c], red); if (threadIdx.x == 0) mean[c] = t / (float)HW; }
+    __syncthreads();
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += nblk * 256) {
+    const h16x4 v = *(const h16x4*)(style + (int64_t)p * 4);
+    for (int c = 0; c < 4; ++c) {
+      const float t = pass == 0 ? (float)v[c] : (float)v[c] - mean[c];
+      acc[c] += pass == 0 ? t : t * t;
+    }
+  }
+  for (int c = 0; c < 4; ++c) {
+    const float t = block_sum(acc[c], red);
+    if (threadIdx.x == 0) part[((int64_t)pass * nblk + blockIdx.x) * 4 + c] = t;
+  }
 }
 
 // 64-pixel strip means of noise*(1-mask) + bg*mask (renderManager.py:929-932)
@@ -327,13 +358,19 @@ extern "C" int sr_adain(const float* content, int64_t c_ps, int64_t c_cs, int64_
 
 extern "C" int sr_noise_pool(const void* noise_f16, const void* alpha_f16, const float* bg, float* pooled, float* out, int32_t H,
                              int32_t W, float* stats, void* stream) {
-  (void)stats;
   if (!noise_f16 || !alpha_f16 || !bg || !pooled || !out) SR_FAIL(SR_ERR_INVALID, "sr_noise_pool: null");
   if (H % 8 || W % 8 || (H * W) % 64) SR_FAIL(SR_ERR_INVALID, "sr_noise_pool: H,W must be multiples of 8");
   hipStream_t st = sr_stream(stream);
   const int ng = H * W / 64;
   hipLaunchKernelGGL(noise_pool_kernel, g1((int64_t)ng * 4), dim3(256), 0, st, (const _Float16*)noise_f16, (const _Float16*)alpha_f16, bg, pooled, ng);
   // AdaIN(content = pooled NHWC (1,h,w,4), style = full-res fp16 noise NHWC) -> (1,4,h,w)
+  if (stats) {                                              // scratch of 2*256*4 floats: style statistics computed chip-wide
+    constexpr int NBLK = 256;
+    hipLaunchKernelGGL(style_partial_rgba16, dim3(NBLK), dim3(256), 0, st, (const _Float16*)noise_f16, H * W, stats, NBLK, 0);
+    hipLaunchKernelGGL(style_partial_rgba16, dim3(NBLK), dim3(256), 0, st, (const _Float16*)noise_f16, H * W, stats, NBLK, 1);
+    hipLaunchKernelGGL(adain_kernel<_Float16>, dim3(4), dim3(256), 0, st, pooled, (int64_t)4, (int64_t)1, (int64_t)0, ng,
+                       (const _Float16*)noise_f16, (int64_t)4, (int64_t)1, (int64_t)0, H * W, out, 4, 1e-5f, 1, stats, NBLK);
+  } else
   hipLaunchKernelGGL(adain_kernel<_Float16>, dim3(4), dim3(256), 0, st, pooled, (int64_t)4, (int64_t)1, (int64_t)0, ng, (const _Float16*)noise_f16,
                      (int64_t)4, (int64_t)1, (int64_t)0, H * W, out, 4, 1e-5f, 1);
   SR_CHECK_LAUNCH("sr_noise_pool");

@@ -273,7 +273,10 @@ def noise_pool(noise_f16, alpha_f16, bg_f32):
     H, W = noise_f16.shape[1:3]
     pooled = torch.empty(H // 8, W // 8, 4, dtype=torch.float32, device=noise_f16.device)
     out = torch.empty(1, 4, H // 8, W // 8, dtype=torch.float32, device=noise_f16.device)
-    L.check(L.lib().sr_noise_pool(_p(noise_f16), _p(alpha_f16), _p(bg_f32), _p(pooled), _p(out), H, W, None, stream_ptr()))
+    key = "np" + str(noise_f16.device)
+    if key not in _WS:
+        _WS[key] = torch.empty(2048, dtype=torch.float32, device=noise_f16.device)
+    L.check(L.lib().sr_noise_pool(_p(noise_f16), _p(alpha_f16), _p(bg_f32), _p(pooled), _p(out), H, W, _p(_WS[key]), stream_ptr()))
     return pooled, out
 
 
