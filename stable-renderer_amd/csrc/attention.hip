@@ -471,7 +471,9 @@ __global__ __launch_bounds__(256, MB) void attn_pipe_kernel(const sr_attention_a
       if (t + 3 < NT) gload((t + 3) * KV_TILE);
     }
     uint4 pf[2][QT];
-    rescale();                                               // alpha of tile t (from the previous iteration's rowmax)
+    // alpha of tile t (from the previous iteration's rowmax); once the running maxima settle every alpha is exactly 1 and
+    // the 12 packed multiplies are skipped (wave-uniform branch ahead of the pipelined body, which stays one block)
+    if (__any(alpha[0] != 1.0f) || __any(alpha[1] != 1.0f)) rescale();
     if (has_next) qk(sn, s1);
     expo(sc, pf);
     if constexpr (STEADY) {

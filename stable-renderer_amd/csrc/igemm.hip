@@ -18,6 +18,157 @@
 
 namespace {
 
+// Row-major epilogue shared by the tile kernels: bias / time-embedding slice / activation in registers, the wave's sub-tile
+// staged through LDS (`smem`, LDS_AVAIL bytes free for it) for 16-byte coalesced stores and residual loads.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int LDS_AVAIL, bool BLOCK_SYNC = true>
+__device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], char* smem, const int M,
+                                              const int rpb, const int m0, const int n0, const int pm0, const int qn0, const int wv,
+                                              const int lane) {
+  constexpr int NW = WAVES_M * WAVES_N, TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const float scale = p.scale;
+  const int N = p.N;
+  const int ldr = p.rowvec_ld ? p.rowvec_ld : N;
+  {
+    const int ldo = (p.act == 2) ? (N >> 1) : N;
+    const bool o32 = p.out_f32 || sizeof(T) == 4;
+    const int oes = o32 ? 4 : 2;                             // output element size
+    if ((ldo * oes) % 16 == 0) {
+      // Coalesced path: bias / time-embedding / activation in registers, then the wave's sub-tile goes through LDS
+      // (the staging buffers are free now) so that global stores -- and the residual loads -- are whole 16-byte
+      // chunks of contiguous rows instead of 4..8-byte pieces scattered over 16 rows per instruction.
+      constexpr int WCOLS = BN / WAVES_N;                    // columns of this wave's sub-tile before GEGLU
+      // rows of the wave's sub-tile staged per pass: all of them when that fits the staging LDS, else 16 (the 256x320 tile)
+      constexpr int TMP = (NW * (BM / WAVES_M) * (WCOLS * 4 + 16) <= LDS_AVAIL) ? TM : 1;
+      const int ocols = (p.act == 2) ? WCOLS / 2 : WCOLS;
+      const int rowb = ocols * oes + 16;                     // padded LDS row (bank spread, keeps 16-B alignment)
+      if constexpr (BLOCK_SYNC) __syncthreads();             // every wave is done reading the staging tiles
+      char* wl = smem + wv * ((TMP * 16) * rowb);
+      const int cpr = ocols * oes / 16;                      // 16-B chunks per row
+      const int rpi = 64 / cpr;                              // rows per wave instruction
+      const int lr = lane / cpr, lc = lane - lr * cpr;
+      const int ncol0 = (p.act == 2) ? ((n0 + qn0) >> 1) : (n0 + qn0);
+      const int epc_o = 16 / oes;
+#pragma unroll
+     for (int tm0 = 0; tm0 < TM; tm0 += TMP) {
+#pragma unroll
+      for (int tm = tm0; tm < tm0 + TMP; ++tm) {
+        const int m = m0 + pm0 + tm * 16 + c16;
+        const int b = (m < M) ? m / rpb : 0;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int n = n0 + qn0 + tn * 16 + 4 * g4;
+          float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
+          if (n < N) {                                       // N % 4 == 0 on this path
+            if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+            if (p.rowvec) { const float4 rv = *(const float4*)(p.rowvec + (int64_t)b * ldr + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+          }
+          if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
+          else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
+          else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
+          char* dst = wl + ((tm - tm0) * 16 + c16) * rowb;
+          if (p.act == 2) {
+            const float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
+            const int col = tn * 8 + 2 * g4;
+            if (o32) *(float2*)(dst + col * 4) = make_float2(o0, o1);
+            else { h16x2 hv = {(_Float16)o0, (_Float16)o1}; *(h16x2*)(dst + col * 2) = hv; }
+          } else {
+            const int col = tn * 16 + 4 * g4;
+            if (o32) *(float4*)(dst + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            else { h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; *(h16x4*)(dst + col * 2) = hv; }
+          }
+        }
+      }
+      // read back row-wise (same wave wrote it: no block barrier needed, only the LDS write->read ordering)
+      __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+      for (int r0 = 0; r0 < TMP * 16; r0 += rpi) {
+        const int row = r0 + lr;
+        if (lr >= rpi || row >= TMP * 16) continue;
+        const int m = m0 + pm0 + tm0 * 16 + row, ncol = ncol0 + lc * epc_o;
+        if (m >= M || ncol >= ldo) continue;
+        uint4 raw = *(const uint4*)(wl + row * rowb + lc * 16);
+        const int64_t oi = (int64_t)m * ldo + ncol;
+        if (p.residual) {
+          if constexpr (sizeof(T) == 2) {
+            if (o32) {                                     // fp32 out + fp16 residual: 4 values per 16-byte out chunk
+              float4 f = __builtin_bit_cast(float4, raw);
+              const h16x4 r4 = *(const h16x4*)((const _Float16*)p.residual + oi);
+              f.x += (float)r4[0]; f.y += (float)r4[1]; f.z += (float)r4[2]; f.w += (float)r4[3];
+              raw = __builtin_bit_cast(uint4, f);
+            } else {
+              const h16x8 rr = *(const h16x8*)((const _Float16*)p.residual + oi);
+              h16x8 hv = __builtin_bit_cast(h16x8, raw);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) hv[e] = (_Float16)((float)hv[e] + (float)rr[e]);
+              raw = __builtin_bit_cast(uint4, hv);
+            }
+          } else {
+            float4 f = __builtin_bit_cast(float4, raw);
+            const float4 rr = *(const float4*)((const float*)p.residual + oi);
+            f.x += rr.x; f.y += rr.y; f.z += rr.z; f.w += rr.w;
+            raw = __builtin_bit_cast(uint4, f);
+          }
+        }
+        *(uint4*)((char*)p.out + oi * oes) = raw;
+      }
+      __builtin_amdgcn_wave_barrier();                       // (LDS is in order per wave: the next pass may overwrite)
+     }
+      return;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + pm0 + tm * 16 + c16;
+      if (m >= M) continue;
+      const int b = m / rpb;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + qn0 + tn * 16 + 4 * g4;
+        if (n >= N) continue;
+        float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
+        const int nv = (N - n) < 4 ? (N - n) : 4;
+        if (p.bias) { for (int r = 0; r < nv; ++r) v[r] += p.bias[n + r]; }
+        if (p.rowvec) { for (int r = 0; r < nv; ++r) v[r] += p.rowvec[(int64_t)b * ldr + n + r]; }
+        if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
+        else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
+        else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
+        if (p.act == 2) {                                // GEGLU: (value, gate) pairs interleaved along n
+          float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
+          const int64_t oi = (int64_t)m * ldo + (n >> 1);
+          if (p.residual) { o0 += sr_load_f((const T*)p.residual + oi); o1 += sr_load_f((const T*)p.residual + oi + 1); }
+          if (p.out_f32) { float* o = (float*)p.out + oi; o[0] = o0; o[1] = o1; }
+          else { T* o = (T*)p.out + oi; sr_store_f(o, o0); sr_store_f(o + 1, o1); }
+          continue;
+        }
+        const int64_t oi = (int64_t)m * ldo + n;
+        if (nv == 4) {
+          if (p.residual) {
+            if constexpr (sizeof(T) == 2) {
+              const h16x4 rr = *(const h16x4*)((const T*)p.residual + oi);
+              v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
+            } else {
+              const float4 rr = *(const float4*)((const float*)p.residual + oi);
+              v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+          }
+          if (p.out_f32 || sizeof(T) == 4) {
+            *(float4*)((float*)p.out + oi) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *(h16x4*)((_Float16*)p.out + oi) = hv;
+          }
+        } else {
+          for (int r = 0; r < nv; ++r) {
+            float o = v[r];
+            if (p.residual) o += sr_load_f((const T*)p.residual + oi + r);
+            if (p.out_f32) ((float*)p.out)[oi + r] = o; else sr_store_f((T*)p.out + oi + r, o);
+          }
+        }
+      }
+    }
+  }
+}
+
 // BKB = bytes of K per LDS stage: 128 (two MFMA k-substeps, 8 rows x 8 chunks per LDS-DMA instruction) or 64 (one k-substep,
 // 16 rows x 4 chunks) -- the 64-byte form halves a stage so that the 256x320 tile gets a FOUR-deep ring in 144 KB (three
 // K-steps of loads in flight instead of one: that tile is otherwise bound by the exposed load latency of every K-step).
@@ -210,142 +361,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
       for (int tm = 0; tm < TM; ++tm) ws[(tn * TM + tm) * 64] = acc[tn][tm];
     return;
   } else if constexpr (!TRANS) {
-    const int ldo = (p.act == 2) ? (N >> 1) : N;
-    const bool o32 = p.out_f32 || sizeof(T) == 4;
-    const int oes = o32 ? 4 : 2;                             // output element size
-    if ((ldo * oes) % 16 == 0) {
-      // Coalesced path: bias / time-embedding / activation in registers, then the wave's sub-tile goes through LDS
-      // (the staging buffers are free now) so that global stores -- and the residual loads -- are whole 16-byte
-      // chunks of contiguous rows instead of 4..8-byte pieces scattered over 16 rows per instruction.
-      constexpr int WCOLS = BN / WAVES_N;                    // columns of this wave's sub-tile before GEGLU
-      // rows of the wave's sub-tile staged per pass: all of them when that fits the staging LDS, else 16 (the 256x320 tile)
-      constexpr int TMP = (NW * (BM / WAVES_M) * (WCOLS * 4 + 16) <= STAGES * STAGE_BYTES) ? TM : 1;
-      const int ocols = (p.act == 2) ? WCOLS / 2 : WCOLS;
-      const int rowb = ocols * oes + 16;                     // padded LDS row (bank spread, keeps 16-B alignment)
-      __syncthreads();                                       // every wave is done reading the staging tiles
-      char* wl = smem + wv * ((TMP * 16) * rowb);
-      const int cpr = ocols * oes / 16;                      // 16-B chunks per row
-      const int rpi = 64 / cpr;                              // rows per wave instruction
-      const int lr = lane / cpr, lc = lane - lr * cpr;
-      const int ncol0 = (p.act == 2) ? ((n0 + qn0) >> 1) : (n0 + qn0);
-      const int epc_o = 16 / oes;
-#pragma unroll
-     for (int tm0 = 0; tm0 < TM; tm0 += TMP) {
-#pragma unroll
-      for (int tm = tm0; tm < tm0 + TMP; ++tm) {
-        const int m = m0 + pm0 + tm * 16 + c16;
-        const int b = (m < M) ? m / rpb : 0;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int n = n0 + qn0 + tn * 16 + 4 * g4;
-          float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
-          if (n < N) {                                       // N % 4 == 0 on this path
-            if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
-            if (p.rowvec) { const float4 rv = *(const float4*)(p.rowvec + (int64_t)b * ldr + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
-          }
-          if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
-          else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
-          else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
-          char* dst = wl + ((tm - tm0) * 16 + c16) * rowb;
-          if (p.act == 2) {
-            const float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
-            const int col = tn * 8 + 2 * g4;
-            if (o32) *(float2*)(dst + col * 4) = make_float2(o0, o1);
-            else { h16x2 hv = {(_Float16)o0, (_Float16)o1}; *(h16x2*)(dst + col * 2) = hv; }
-          } else {
-            const int col = tn * 16 + 4 * g4;
-            if (o32) *(float4*)(dst + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            else { h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; *(h16x4*)(dst + col * 2) = hv; }
-          }
-        }
-      }
-      // read back row-wise (same wave wrote it: no block barrier needed, only the LDS write->read ordering)
-      __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
-      __builtin_amdgcn_wave_barrier();
-      for (int r0 = 0; r0 < TMP * 16; r0 += rpi) {
-        const int row = r0 + lr;
-        if (lr >= rpi || row >= TMP * 16) continue;
-        const int m = m0 + pm0 + tm0 * 16 + row, ncol = ncol0 + lc * epc_o;
-        if (m >= M || ncol >= ldo) continue;
-        uint4 raw = *(const uint4*)(wl + row * rowb + lc * 16);
-        const int64_t oi = (int64_t)m * ldo + ncol;
-        if (p.residual) {
-          if constexpr (sizeof(T) == 2) {
-            if (o32) {                                     // fp32 out + fp16 residual: 4 values per 16-byte out chunk
-              float4 f = __builtin_bit_cast(float4, raw);
-              const h16x4 r4 = *(const h16x4*)((const _Float16*)p.residual + oi);
-              f.x += (float)r4[0]; f.y += (float)r4[1]; f.z += (float)r4[2]; f.w += (float)r4[3];
-              raw = __builtin_bit_cast(uint4, f);
-            } else {
-              const h16x8 rr = *(const h16x8*)((const _Float16*)p.residual + oi);
-              h16x8 hv = __builtin_bit_cast(h16x8, raw);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) hv[e] = (_Float16)((float)hv[e] + (float)rr[e]);
-              raw = __builtin_bit_cast(uint4, hv);
-            }
-          } else {
-            float4 f = __builtin_bit_cast(float4, raw);
-            const float4 rr = *(const float4*)((const float*)p.residual + oi);
-            f.x += rr.x; f.y += rr.y; f.z += rr.z; f.w += rr.w;
-            raw = __builtin_bit_cast(uint4, f);
-          }
-        }
-        *(uint4*)((char*)p.out + oi * oes) = raw;
-      }
-      __builtin_amdgcn_wave_barrier();                       // (LDS is in order per wave: the next pass may overwrite)
-     }
-      return;
-    }
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int m = m0 + pm0 + tm * 16 + c16;
-      if (m >= M) continue;
-      const int b = m / rpb;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + qn0 + tn * 16 + 4 * g4;
-        if (n >= N) continue;
-        float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
-        const int nv = (N - n) < 4 ? (N - n) : 4;
-        if (p.bias) { for (int r = 0; r < nv; ++r) v[r] += p.bias[n + r]; }
-        if (p.rowvec) { for (int r = 0; r < nv; ++r) v[r] += p.rowvec[(int64_t)b * ldr + n + r]; }
-        if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
-        else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
-        else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
-        if (p.act == 2) {                                // GEGLU: (value, gate) pairs interleaved along n
-          float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
-          const int64_t oi = (int64_t)m * ldo + (n >> 1);
-          if (p.residual) { o0 += sr_load_f((const T*)p.residual + oi); o1 += sr_load_f((const T*)p.residual + oi + 1); }
-          if (p.out_f32) { float* o = (float*)p.out + oi; o[0] = o0; o[1] = o1; }
-          else { T* o = (T*)p.out + oi; sr_store_f(o, o0); sr_store_f(o + 1, o1); }
-          continue;
-        }
-        const int64_t oi = (int64_t)m * ldo + n;
-        if (nv == 4) {
-          if (p.residual) {
-            if constexpr (sizeof(T) == 2) {
-              const h16x4 rr = *(const h16x4*)((const T*)p.residual + oi);
-              v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3];
-            } else {
-              const float4 rr = *(const float4*)((const float*)p.residual + oi);
-              v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            }
-          }
-          if (p.out_f32 || sizeof(T) == 4) {
-            *(float4*)((float*)p.out + oi) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            *(h16x4*)((_Float16*)p.out + oi) = hv;
-          }
-        } else {
-          for (int r = 0; r < nv; ++r) {
-            float o = v[r];
-            if (p.residual) o += sr_load_f((const T*)p.residual + oi + r);
-            if (p.out_f32) ((float*)p.out)[oi + r] = o; else sr_store_f((T*)p.out + oi + r, o);
-          }
-        }
-      }
-    }
+    epilogue_rows<T, BM, BN, WAVES_M, WAVES_N, STAGES * STAGE_BYTES>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
   } else {
     const bool vec = (rpb % 4 == 0) && (p.ldt % 4 == 0);
 #pragma unroll
@@ -398,6 +414,11 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   return SR_OK;
 }
 
+// (A persistent "K-step stream" form of the 256x320 tile -- one workgroup per CU walking its tiles through the two LDS
+//  buffers, the next tile's first K-step prefetched under the epilogue -- was built and measured for the K-short GEGLU layers:
+//  parity-clean but slower, 383-431 vs 276 us at M65536 K320 N2560: keeping the next tile's bookkeeping alive beside 160
+//  accumulators and the epilogue temporaries spills 276-412 bytes per lane into the epilogue, and the asm-issued LDS-DMA loop
+//  alone is 9 % behind the builtin one.  Left out; the remaining lever for those layers is a smaller accumulator footprint.)
 // out = act(scale * sum_z ws[z] + bias + rowvec) + residual for the tiles [tile0, tile0+nwg) of a split launch; a block
 // owns one (tn, tm) fragment of each of the tile's 4 waves and reads the partials in the layout the GEMM wrote (1 KiB
 // per wave instruction), fixed z order.
@@ -516,6 +537,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // measured 830 vs 627 TF/s on the 64x64 C320 3x3 conv, 1086 vs 1000 on C1280, but 556 vs 678 at 32x32 C640.
     if ((force == 5 || force == 6) && a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d (256x320) needs N %% 320 == 0, N=%d", force, a.N);
     if (force == 6) return launch<T, 256, 320, 4, 2, 4, TRANS, 64>(a, M, Ho, Wo, st);
+
     if (force == 5 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) >= 256))
       return launch<T, 256, 320, 4, 2, 2, TRANS>(a, M, Ho, Wo, st);
   } else {
