@@ -71,10 +71,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # one process per GPU; SR_DIST_BACKEND=gloo lets the multi-process path be rehearsed on a box with fewer GPUs than ranks
+    # (ranks then share devices, collectives are staged through the host)
+    backend = os.environ.get("SR_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     from stable_renderer_amd import _lib as L
     from stable_renderer_amd.pipeline import build_sd15_pipeline
@@ -104,7 +111,7 @@ def main():
     sync()
     dt = max(time.perf_counter() - t0, 1e-9)
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     frames = a.views * a.steps * (1 if shard is not None else world)
