@@ -128,10 +128,16 @@ int sr_add_scaled(const void* a, const void* b, void* y, int64_t n, float s, int
  * builds it once per (model, batch, resolution); no Python in the per-step path).  */
 typedef enum {
   SR_OP_IGEMM = 1, SR_OP_GROUPNORM = 2, SR_OP_LAYERNORM = 3, SR_OP_ATTENTION = 4, SR_OP_NCHW_TO_NHWC = 5,
-  SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9, SR_OP_GATHER_ROWS = 10, SR_OP_ADD_SCALED = 11
+  SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9, SR_OP_GATHER_ROWS = 10, SR_OP_ADD_SCALED = 11,
+  SR_OP_FORK = 12,   /* side lane may start: it waits for everything issued on the main lane so far                       */
+  SR_OP_JOIN = 13    /* main lane waits for everything issued on the side lane so far                                     */
 } sr_op_kind;
+/* lane: 0 = the caller's stream, 1 = the executor's side stream.  Independent branches of the graph (a ResBlock's 1x1
+ * skip convolution beside its GroupNorm/conv path; the injected frame's K/V projections beside the Q projection) are
+ * emitted as FORK, side-lane ops, main-lane ops ..., JOIN: many UNet kernels are single-round or latency-bound, so a second
+ * lane fills their ramps and tails.  In a captured plan the two lanes become parallel branches of the hipGraph. */
 typedef struct {
-  int32_t kind; int32_t pad_;
+  int32_t kind; int32_t lane;
   union {
     sr_igemm_args igemm;
     sr_groupnorm_args gn;

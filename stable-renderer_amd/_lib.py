@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsr_hip.so")
 
 SR_F16, SR_F32 = 0, 1
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_TIMESTEP_EMBED, OP_SILU,
- OP_SOFTMAX_ROWS, OP_GATHER_ROWS, OP_ADD_SCALED) = range(1, 12)
+ OP_SOFTMAX_ROWS, OP_GATHER_ROWS, OP_ADD_SCALED, OP_FORK, OP_JOIN) = range(1, 14)
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -66,7 +66,7 @@ class _OpU(C.Union):
 
 
 class Op(C.Structure):
-    _fields_ = [("kind", i32), ("pad_", i32), ("u", _OpU)]
+    _fields_ = [("kind", i32), ("lane", i32), ("u", _OpU)]
 
 
 class Draw(C.Structure):

@@ -26,16 +26,49 @@ static int run_op(const sr_op& op, void* stream) {
   }
 }
 
+// side lane: one extra stream per process + two events (fork / join).  Re-recording an event is safe here: a wait
+// captures the record that precedes it in program order, eagerly and under stream capture alike.
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_fork = nullptr, g_join = nullptr;
+static int side_init() {
+  if (g_side) return SR_OK;
+  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "side stream");
+  if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess)
+    SR_FAIL(SR_ERR_LAUNCH, "side events");
+  return SR_OK;
+}
+
 extern "C" int sr_plan_run(const sr_op* ops, int32_t n, void* stream) {
   if (!ops || n < 0) SR_FAIL(SR_ERR_INVALID, "sr_plan_run: bad args");
+  bool side_open = false;                                    // side-lane work issued since the last JOIN
   for (int i = 0; i < n; ++i) {
-    const int rc = run_op(ops[i], stream);
+    if (ops[i].kind == SR_OP_FORK || ops[i].kind == SR_OP_JOIN || ops[i].lane == 1) {
+      if (side_init() != SR_OK) return SR_ERR_LAUNCH;
+    }
+    if (ops[i].kind == SR_OP_FORK) {
+      if (hipEventRecord(g_fork, sr_stream(stream)) != hipSuccess || hipStreamWaitEvent(g_side, g_fork, 0) != hipSuccess)
+        SR_FAIL(SR_ERR_LAUNCH, "sr_plan_run: fork at op %d", i);
+      side_open = true;
+      continue;
+    }
+    if (ops[i].kind == SR_OP_JOIN) {
+      if (side_open && (hipEventRecord(g_join, g_side) != hipSuccess || hipStreamWaitEvent(sr_stream(stream), g_join, 0) != hipSuccess))
+        SR_FAIL(SR_ERR_LAUNCH, "sr_plan_run: join at op %d", i);
+      side_open = false;
+      continue;
+    }
+    if (ops[i].lane == 1 && !side_open) SR_FAIL(SR_ERR_INVALID, "sr_plan_run: side-lane op %d outside FORK..JOIN", i);
+    const int rc = run_op(ops[i], ops[i].lane == 1 ? (void*)g_side : stream);
     if (rc != SR_OK) {
       char buf[400];
       snprintf(buf, sizeof(buf), "%s", sr_last_error());
       sr_set_error("plan op %d (kind %d): %s", i, ops[i].kind, buf);
       return rc;
     }
+  }
+  if (side_open) {                                           // a plan must not end with the side lane detached
+    if (hipEventRecord(g_join, g_side) != hipSuccess || hipStreamWaitEvent(sr_stream(stream), g_join, 0) != hipSuccess)
+      SR_FAIL(SR_ERR_LAUNCH, "sr_plan_run: final join");
   }
   return SR_OK;
 }

@@ -108,14 +108,14 @@ def autotune_enabled():
     return os.environ.get("SR_AUTOTUNE", "1") != "0" and torch.cuda.is_available()
 
 
-def tune_igemm(ar, min_flops=1.0e9, reps=4):
+def tune_igemm(ar, min_flops=1.0e9, reps=4, allow_split=True):
     """times the candidate (tile, split) settings of one op on the current stream and leaves the fastest in ``ar``"""
     Ho, Wo = (2 * ar.H, 2 * ar.W) if ar.upsample else ((ar.H + ar.stride - 1) // ar.stride, (ar.W + ar.stride - 1) // ar.stride)
     flops = 2.0 * ar.B * Ho * Wo * ar.N * ar.KH * ar.KH * (ar.C1 + ar.C2)
     if flops < min_flops:
         return
     sig = (ar.dtype, ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample, ar.act, ar.transpose_out, ar.out_f32,
-           bool(ar.residual), bool(ar.rowvec))
+           bool(ar.residual), bool(ar.rowvec), bool(allow_split))
     if sig not in _TUNED:
         lib, st = L.lib(), stream_ptr()
         times = {}
@@ -123,6 +123,8 @@ def tune_igemm(ar, min_flops=1.0e9, reps=4):
             for tile, split in _CANDIDATES:
                 if (ar.act == 2 or ar.transpose_out) and split == 0 and tile != 0:
                     continue                                 # these never split: (tile, 0) == (tile, -1)
+                if not allow_split and split == 0:
+                    continue
                 if rnd == 1 and (tile, split) not in times:
                     continue
                 ar.tile, ar.split = tile, split
@@ -137,7 +139,7 @@ def tune_igemm(ar, min_flops=1.0e9, reps=4):
                 e1.synchronize()
                 t = e0.elapsed_time(e1) / n
                 times[(tile, split)] = min(t, times.get((tile, split), t)) if rnd == 1 else t
-        best, best_t = (0, 0), None
+        best, best_t = (0, 0 if allow_split else -1), None
         for c in _CANDIDATES:                                # 3 % hysteresis towards the earlier (heuristic-first) entry
             if c in times and (best_t is None or times[c] < best_t * 0.97):
                 best, best_t = c, times[c]

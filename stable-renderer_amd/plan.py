@@ -1,6 +1,7 @@
 """Launch plans: a model forward lowered once to a flat array of C-ABI ops (include/sr_hip.h: sr_op) over
 pre-allocated HBM buffers, then replayed natively (eagerly or as a hipGraph) every denoise step."""
 import ctypes as C
+import os
 
 import torch
 
@@ -21,9 +22,16 @@ class Plan:
         L.check(L.lib().sr_plan_run(self.ops, self.n, O.stream_ptr()))
 
     def subset(self, kind):
-        """-> Plan holding only the ops of one kind (same buffers): used to time one kernel family in isolation"""
+        """-> Plan holding only the ops of one kind (same buffers), all on the main lane: used to time one kernel family
+        in isolation"""
         idx = [i for i in range(self.n) if self.ops[i].kind == kind]
-        return Plan([self.ops[i] for i in idx], self._keep, [self.op_flops[i] for i in idx])
+        sel = []
+        for i in idx:
+            op = L.Op()
+            C.memmove(C.byref(op), C.byref(self.ops[i]), C.sizeof(L.Op))
+            op.lane = 0
+            sel.append(op)
+        return Plan(sel, self._keep, [self.op_flops[i] for i in idx])
 
     def capture(self, stream):
         """capture into a hipGraph on `stream` (a torch.cuda.Stream, not the default one)"""
@@ -54,6 +62,32 @@ class PlanBuilder:
         self.keep = []
         self._gn_scratch = None
         self.flops = 0
+        self._lane = 0
+        # Side lane off by default: measured on the SD1.5 UNet step (skip convolutions and the injected frame's K/V
+        # projections beside the main chain) it is neutral under a hipGraph (24.15 vs 24.00 ms) and costs 1 ms eagerly
+        # (60 event record/wait pairs); SR_TWO_LANES=1 turns it on.
+        self.two_lanes = os.environ.get("SR_TWO_LANES", "0") == "1"
+
+    # ---- side lane (include/sr_hip.h: SR_OP_FORK / SR_OP_JOIN) -----------------------------------------
+    def fork(self):
+        if self.two_lanes:
+            self._emit(L.OP_FORK, None, None)
+
+    def join(self):
+        if self.two_lanes:
+            self._emit(L.OP_JOIN, None, None)
+
+    def side(self):
+        """context manager: ops emitted inside run on the side lane (between fork() and join())"""
+        pb = self
+
+        class _Side:
+            def __enter__(self_inner):
+                pb._lane = 1 if pb.two_lanes else 0
+
+            def __exit__(self_inner, *a):
+                pb._lane = 0
+        return _Side()
 
     def buf(self, *shape, dtype=None, zero=False):
         t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype or self.dtype, device=self.device)
@@ -66,7 +100,9 @@ class PlanBuilder:
     def _emit(self, kind, field, args):
         op = L.Op()
         op.kind = kind
-        setattr(op.u, field, args)
+        op.lane = self._lane if field is not None else 0
+        if field is not None:
+            setattr(op.u, field, args)
         self.ops.append(op)
         self.op_flops.append(0)
 
@@ -74,8 +110,10 @@ class PlanBuilder:
     def igemm(self, a, w, out, B, H, W, C1, N, **kw):
         self.hold(a, w, out, kw.get("a2"), kw.get("bias"), kw.get("rowvec"), kw.get("residual"))
         ar = O.igemm_args(a, w, out, B, H, W, C1, N, dtype=self.dtype, **kw)
+        if self._lane == 1:
+            ar.split = -1                      # the split-K workspace belongs to the main lane
         if O.autotune_enabled():
-            O.tune_igemm(ar)
+            O.tune_igemm(ar, allow_split=self._lane == 0)
         self._emit(L.OP_IGEMM, "igemm", ar)
         KH, st, up = kw.get("KH", 1), kw.get("stride", 1), kw.get("upsample", 0)
         Ho, Wo = (2 * H, 2 * W) if up else ((H + st - 1) // st, (W + st - 1) // st)

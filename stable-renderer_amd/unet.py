@@ -98,18 +98,24 @@ class BlockLowering:
         else:
             er, er_ld = pb.buf(B, Cout, dtype=torch.float32), 0
             pb.igemm(emb_s, W[p + ".emb_layers.1"], er, B, 1, 1, 4 * mc, Cout, bias=W[p + ".emb_layers.1.b"], out_f32=1)
+        has_skip = (p + ".skip_connection") in W
+        if has_skip:
+            # the 1x1 skip convolution only needs the block input: side lane, beside the GroupNorm / conv path
+            skip = pb.buf(B, HW, Cout)
+            pb.fork()
+            with pb.side():
+                pb.igemm(x1, W[p + ".skip_connection"], skip, B, hh, ww, C1, Cout, a2=x2, C2=C2, bias=W[p + ".skip_connection.b"])
+        else:
+            assert x2 is None and C1 == Cout
+            skip = x1
         n1 = pb.buf(B, HW, cin)
         pb.groupnorm(x1, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.beta"], n1, B, HW, C1, x2=x2, C2=C2, eps=1e-5, silu=True)
         hmid = pb.buf(B, HW, Cout)
         pb.igemm(n1, W[p + ".in_layers.2"], hmid, B, hh, ww, cin, Cout, KH=3, bias=W[p + ".in_layers.2.b"], rowvec=er, rowvec_ld=er_ld)
         n2 = pb.buf(B, HW, Cout)
         pb.groupnorm(hmid, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.beta"], n2, B, HW, Cout, eps=1e-5, silu=True)
-        if (p + ".skip_connection") in W:
-            skip = pb.buf(B, HW, Cout)
-            pb.igemm(x1, W[p + ".skip_connection"], skip, B, hh, ww, C1, Cout, a2=x2, C2=C2, bias=W[p + ".skip_connection.b"])
-        else:
-            assert x2 is None and C1 == Cout
-            skip = x1
+        if has_skip:
+            pb.join()
         out = pb.buf(B, HW, Cout)
         pb.igemm(n2, W[p + ".out_layers.3"], out, B, hh, ww, Cout, Cout, KH=3, bias=W[p + ".out_layers.3.b"], residual=skip)
         return out
@@ -122,8 +128,8 @@ class BlockLowering:
         ln = pb.buf(B, HW, Cc)
         pb.layernorm(hcur, W[p + ".norm1.g"], W[p + ".norm1.beta"], ln, B * HW, Cc)
         q = pb.buf(B, HW, Cc)
-        pb.igemm(ln, W[p + ".attn1.to_q"], q, B * HW, 1, 1, Cc, Cc)
         if inject_idx is None:
+            pb.igemm(ln, W[p + ".attn1.to_q"], q, B * HW, 1, 1, Cc, Cc)
             Bk, Tk, ldt = B, HW, _cdiv(HW, 8) * 8     # V^T rows padded to 16 B (pad columns stay zero)
             k = pb.buf(B, HW, Cc)
             vt = pb.buf(B, Cc, ldt, zero=True)
@@ -139,10 +145,15 @@ class BlockLowering:
             if self.external:
                 self.segments.append(pb.take())
                 self.points.append((ln, src))
-            else:
-                pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size())
-            pb.igemm(src, W[p + ".attn1.to_k"], k, Tk, 1, 1, Cc, Cc)
-            pb.igemm(src, W[p + ".attn1.to_v"], vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt)
+            # the injected frame's K / V^T are one-frame GEMMs (latency bound): side lane, beside the B-frame Q projection
+            pb.fork()
+            with pb.side():
+                if not self.external:
+                    pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size())
+                pb.igemm(src, W[p + ".attn1.to_k"], k, Tk, 1, 1, Cc, Cc)
+                pb.igemm(src, W[p + ".attn1.to_v"], vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt)
+            pb.igemm(ln, W[p + ".attn1.to_q"], q, B * HW, 1, 1, Cc, Cc)
+            pb.join()
         a = pb.buf(B, HW, Cc)
         pb.attention(q, k, vt, a, B, Bk, HW, Tk, heads, d, ldt)
         h1 = pb.buf(B, HW, Cc)

@@ -122,3 +122,35 @@ def test_controlnet_into_unet(dtype, atol):
     y = up["out"].cpu()
     ref = T(d["y"])
     assert (y - ref).abs().max().item() < atol * max(1.0, ref.abs().max().item()), (y - ref).abs().max()
+
+
+def test_plan_side_lane_fork_join():
+    """SR_OP_FORK / side-lane ops / SR_OP_JOIN: eager and captured replays give the single-lane result"""
+    from stable_renderer_amd.plan import PlanBuilder
+    dev = torch.device("cuda")
+    pb = PlanBuilder(dev, torch.float32)
+    pb.two_lanes = True
+    n = 1 << 16
+    g = torch.Generator().manual_seed(5)
+    a, c = pb.buf(n), pb.buf(n)
+    a.copy_(torch.randn(n, generator=g)); c.copy_(torch.randn(n, generator=g))
+    b, d, e = pb.buf(n), pb.buf(n), pb.buf(n)
+    pb.fork()
+    with pb.side():
+        pb.silu(a, b)
+    pb.silu(c, d)
+    pb.join()
+    pb.add(b, d, e, s=2.0)
+    plan = pb.take()
+    assert [plan.ops[i].lane for i in range(plan.n)] == [0, 1, 0, 0, 0]
+    ref = torch.nn.functional.silu(a) + 2.0 * torch.nn.functional.silu(c)
+    plan.run()
+    torch.cuda.synchronize()
+    assert torch.allclose(e, ref, atol=1e-6)
+    e.zero_()
+    st = torch.cuda.Stream()
+    plan.capture(st)
+    with torch.cuda.stream(st):
+        plan.launch()
+    torch.cuda.synchronize()
+    assert torch.allclose(e, ref, atol=1e-6)

@@ -33,11 +33,16 @@ if SEQ:
     seq_us = [0.0] * plan.n
     for _ in range(reps):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(plan.n + 1)]
-        ones = [(L.Op * 1)(plan.ops[i]) for i in range(plan.n)]
+        ones = []
+        for i in range(plan.n):
+            o = (L.Op * 1)(plan.ops[i])
+            o[0].lane = 0                                       # per-op timing: everything on the measured stream
+            ones.append(o)
         torch.cuda.synchronize()
         evs[0].record()
         for i in range(plan.n):
-            lib.sr_plan_run(ones[i], 1, O.stream_ptr())
+            if plan.ops[i].kind < L.OP_FORK:
+                lib.sr_plan_run(ones[i], 1, O.stream_ptr())
             evs[i + 1].record()
         torch.cuda.synchronize()
         for i in range(plan.n):
@@ -49,6 +54,9 @@ for i in range(plan.n):
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         one = (L.Op * 1)(op)
+        one[0].lane = 0
+        if op.kind >= L.OP_FORK:
+            continue
         lib.sr_plan_run(one, 1, O.stream_ptr())
         e0.record()
         for _ in range(reps):
@@ -75,7 +83,30 @@ for i in range(plan.n):
     agg[sig][1] += 1
     agg[sig][2] += plan.op_flops[i]
 tot = sum(v[0] for v in agg.values())
-print(f"total {tot/1e3:.2f} ms over {plan.n} ops")
+print(f"total {tot/1e3:.2f} ms over {plan.n} ops (serialised per-op sum)")
+# whole plan as it really runs (both lanes), eager
+for _ in range(2):
+    plan.run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    plan.run()
+e1.record()
+torch.cuda.synchronize()
+print(f"whole plan, two lanes, eager: {e0.elapsed_time(e1) / 5:.2f} ms")
+st = torch.cuda.Stream()
+plan.capture(st)
+torch.cuda.synchronize()
+with torch.cuda.stream(st):
+    for _ in range(2):
+        plan.launch()
+    e0.record()
+    for _ in range(5):
+        plan.launch()
+    e1.record()
+torch.cuda.synchronize()
+print(f"whole plan, hipGraph: {e0.elapsed_time(e1) / 5:.2f} ms")
 for sig, (us, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
     tf = fl / (us * 1e-6) / 1e12 if us > 0 else 0
     print(f"{us/1e3:8.3f} ms {100*us/tot:5.1f}%  n={n:3d} avg {us/n:8.1f} us {tf:7.1f} TF/s  {sig}")
