@@ -419,6 +419,12 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
 //  parity-clean but slower, 383-431 vs 276 us at M65536 K320 N2560: keeping the next tile's bookkeeping alive beside 160
 //  accumulators and the epilogue temporaries spills 276-412 bytes per lane into the epilogue, and the asm-issued LDS-DMA loop
 //  alone is 9 % behind the builtin one.  Left out; the remaining lever for those layers is a smaller accumulator footprint.)
+// (Second persistent attempt, also measured and dropped: the 256x128 tile (64 accumulators per lane, 163 VGPRs, no spills) as a
+//  one-workgroup-per-CU stream through the 3-slot ring -- load cursor two K-steps ahead ACROSS tile boundaries, epilogue out
+//  of the slot just consumed, store-aware counted vmcnt.  Parity-clean incl. ragged tiles, but 277 vs 280 us on the 64x64
+//  GEGLU layer and 2074 vs 1956 us on the big conv: with all eight waves in lockstep the epilogue is still a phase in which
+//  the MFMA pipe idles; overlapping it needs a second, independently phased workgroup on the CU, which LDS does not allow
+//  for tiles with enough FLOP per staged byte.)
 // out = act(scale * sum_z ws[z] + bias + rowvec) + residual for the tiles [tile0, tile0+nwg) of a split launch; a block
 // owns one (tn, tm) fragment of each of the tile's 4 waves and reads the partials in the layout the GEMM wrote (1 KiB
 // per wave instruction), fixed z order.

@@ -63,6 +63,9 @@ for sh in shapes:
             os.environ["SR_IGEMM_TILE"] = str(tile)
         else:
             os.environ.pop("SR_IGEMM_TILE", None)
-        us, tf = run(*sh)
-        row.append(f"t{tile}:{us:7.1f}us {tf:6.0f}TF")
+        try:
+            us, tf = run(*sh)
+            row.append(f"t{tile}:{us:7.1f}us {tf:6.0f}TF")
+        except Exception:
+            row.append(f"t{tile}:     n/a         ")
     print("B%d %dx%d C%d N%d k%d act%d | " % sh + " | ".join(row), flush=True)
