@@ -10,7 +10,9 @@
 //     stride 2, channel-concat of two sources) is just the per-lane source address.
 //   * each wave multiplies its (BM/WAVES_M) x (BN/WAVES_N) sub-tile with v_mfma_f32_16x16x32_f16 (fp16) or
 //     v_mfma_f32_16x16x4_f32 (exact fp32) out of the current buffer.
-// One barrier per K-step, two LDS buffers.  Weights are the MFMA "A" operand so that every lane ends up
+// One barrier per K-step, a ring of 2..4 LDS slots with the loads 1..3 K-steps ahead.  The LDS-DMA is issued from inline asm
+// and ordered by hand (counted s_waitcnt vmcnt + raw s_barrier): hipcc's own wait-count pass would drain every in-flight
+// LDS-DMA before the next ds_read.  Weights are the MFMA "A" operand so that every lane ends up
 // holding 4 consecutive output channels of one pixel (8/16-byte stores, vector bias/residual loads); with
 // transpose_out the roles swap and a lane holds 4 consecutive pixels of one channel (V^T for attention).
 #include "sr_common.h"
@@ -263,12 +265,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
     const int off = (fromA ? s_kk : s_kk - K1) * BKB;
     auto gp = [&](int i) { return ((i * NW + wv) < GP ? (i * NW + wv) : GP - 1) * 1024; };   // LDS offset of the row group
     auto gq = [&](int i) { return ((i * NW + wv) < GQ ? (i * NW + wv) : GQ - 1) * 1024; };
-    if constexpr (STAGES == 2) {
-#pragma unroll
-      for (int i = 0; i < NIP; ++i) sr_glds16((fromA ? rowA[i] : rowB[i]) + off, tP + gp(i));
-#pragma unroll
-      for (int i = 0; i < NIQ; ++i) { sr_glds16(wrow[i], tQ + gq(i)); wrow[i] += BKB; }
-    } else {
+    {
       const unsigned lP = __builtin_amdgcn_readfirstlane(sr_lds_addr(tP)), lQ = __builtin_amdgcn_readfirstlane(sr_lds_addr(tQ));
 #pragma unroll
       for (int i = 0; i < NIP; ++i) sr_glds16_asm((fromA ? rowA[i] : rowB[i]) + off, lP + gp(i));
@@ -316,33 +313,31 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
         }
     }
   };
-  if constexpr (STAGES == 2) {
-    const int nk = kt1 - kt0;
-    stage(0);
-    for (int kt = 0; kt < nk; ++kt) {
-      __syncthreads();                                   // (vmcnt(0)+barrier) tile kt landed; buffer kt+1 is free
-      if (kt + 1 < nk) stage((kt + 1) & 1);
-      compute(kt & 1);
-    }
-  } else {
+  {
     // STAGES-deep LDS ring, loads run D = STAGES-1 K-steps ahead: wait only for the oldest stage (counted vmcnt, never 0
     // while a younger stage is in flight) and synchronise with a raw s_barrier so the in-flight LDS-DMA is not drained
     constexpr int PER_STAGE = NIP + NIQ;                 // glds instructions one wave issues per stage (same for every wave)
+    // With two slots (D = 1) this is the plain double buffer, but the LDS-DMA MUST be issued from inline asm: for the
+    // __builtin_amdgcn_global_load_lds form hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read of compute(),
+    // i.e. it drains the prefetch it has just issued and every K-step pays the full load latency (found in the ISA of the
+    // 2-slot kernels; SQ_WAIT_ANY was 49 % of the wave cycles).  asm-issued: 64x64 C320 3x3 conv 146 -> 133 us, big conv
+    // 1094 -> 1186 TF/s, 64x64 GEGLU 265 -> 251 us, and every 128-wide tile likewise.
     constexpr int D = STAGES - 1;
-    static_assert(STAGES == 3 || STAGES == 4, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     static_assert(PER_STAGE * (D - 1) < 64, "vmcnt immediate");
+    const int nk = kt1 - kt0;                            // (split-K: this workgroup's share of the K-steps)
 #pragma unroll
-    for (int i = 0; i < D; ++i) if (i < KT) stage(i);
+    for (int i = 0; i < D; ++i) if (i < nk) stage(i);
     int cur = 0;
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = 0; kt < nk; ++kt) {
       // the asm-issued LDS-DMA is invisible to hipcc's wait-count pass, so these counted waits are the only ordering:
       // leave the min(D-1, remaining) younger stages in flight
-      const int younger = KT - 1 - kt;
+      const int younger = nk - 1 - kt;
       if (younger >= D - 1)                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (D - 1)) : "memory");
       else if (D == 3 && younger == 1)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
       else                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // stage kt visible to all; everyone finished step kt-1
-      if (kt + D < KT) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; stage(nb); }
+      if (kt + D < nk) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; stage(nb); }
       compute(cur);
       if (++cur == STAGES) cur = 0;
     }
