@@ -174,7 +174,7 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
 // BKB = bytes of K per LDS stage: 128 (two MFMA k-substeps, 8 rows x 8 chunks per LDS-DMA instruction) or 64 (one k-substep,
 // 16 rows x 4 chunks) -- the 64-byte form halves a stage so that the 256x320 tile gets a FOUR-deep ring in 144 KB (three
 // K-steps of loads in flight instead of one: that tile is otherwise bound by the exposed load latency of every K-step).
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, bool SPREAD = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
                                                                         const int NT, const int nwg, const int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -313,6 +313,50 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
         }
     }
   };
+  // compute(buf) with the LDS-DMA of a later K-step (ring slot nbuf) issued piecewise BETWEEN the MFMA groups of the first
+  // k-substep instead of in one burst after the barrier: a wave that issues 6..9 LDS-DMA instructions back to back sits
+  // ~100 cycles on each while its SIMD's matrix pipe idles (both waves of a SIMD do this at the same moment).
+  auto compute_staging = [&](int buf, int nbuf) {
+    const char* tP = smem + buf * STAGE_BYTES + pm0 * BKB;
+    const char* tQ = smem + buf * STAGE_BYTES + BM * BKB + qn0 * BKB;
+    char* nP = smem + nbuf * STAGE_BYTES;
+    const unsigned lP = __builtin_amdgcn_readfirstlane(sr_lds_addr(nP)), lQ = __builtin_amdgcn_readfirstlane(sr_lds_addr(nP + BM * BKB));
+    const bool fromA = s_kk < K1;
+    const int off = (fromA ? s_kk : s_kk - K1) * BKB;
+    constexpr int PIECES = NIP + NIQ, PPS = (PIECES + TN - 1) / TN;       // LDS-DMA pieces per MFMA group
+    auto piece = [&](int i) {
+      if (i < NIP) {
+        const int g = ((i * NW + wv) < GP ? (i * NW + wv) : GP - 1) * 1024;
+        sr_glds16_asm((fromA ? rowA[i] : rowB[i]) + off, lP + g);
+      } else if (i < PIECES) {
+        const int q = i - NIP;
+        const int g = ((q * NW + wv) < GQ ? (q * NW + wv) : GQ - 1) * 1024;
+        sr_glds16_asm(wrow[q], lQ + g);
+        wrow[q] += BKB;
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < BKB / 64; ++j) {
+      uint4 xf[TM], wf[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) xf[t] = *(const uint4*)(tP + t * FBLK + foff[j]);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) wf[t] = *(const uint4*)(tQ + t * FBLK + foff[j]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if constexpr (TRANS) sr_mma(acc[tm][tn], xf[tm], wf[tn], T());
+          else                 sr_mma(acc[tn][tm], wf[tn], xf[tm], T());
+        }
+        if (j == 0) {
+#pragma unroll
+          for (int q = 0; q < PPS; ++q) piece(tn * PPS + q);
+        }
+      }
+    }
+    if (++s_kk == KPT) { s_kk = 0; if (++s_tap < ntaps) set_tap(s_tap); }
+  };
   {
     // STAGES-deep LDS ring, loads run D = STAGES-1 K-steps ahead: wait only for the oldest stage (counted vmcnt, never 0
     // while a younger stage is in flight) and synchronise with a raw s_barrier so the in-flight LDS-DMA is not drained
@@ -337,8 +381,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
       else if (D == 3 && younger == 1)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
       else                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // stage kt visible to all; everyone finished step kt-1
-      if (kt + D < nk) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; stage(nb); }
-      compute(cur);
+      if constexpr (SPREAD) {
+        if (kt + D < nk) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; compute_staging(cur, nb); }
+        else compute(cur);
+      } else {
+        if (kt + D < nk) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; stage(nb); }
+        compute(cur);
+      }
       if (++cur == STAGES) cur = 0;
     }
   }
@@ -389,7 +438,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, bool SPREAD = false>
 int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int Npad = (a.N + 127) / 128 * 128;
   const int MT = (M + BM - 1) / BM, NT = Npad / BN;
@@ -400,7 +449,7 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   constexpr int lds_epi_all = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);   // fp32 output sub-tiles of all waves
   constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
   constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB>;
+  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB, SPREAD>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   (void)NT;
@@ -565,8 +614,11 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   }
   // 256x128 tile, 8 waves, 3-deep LDS ring with counted vmcnt: +5..17 % on the large-M layers (measured 1003 vs 858 TF/s
   // on the 64x64x1280 3x3 conv); smaller problems keep the 4-wave 2-stage tiles (finer granularity, same rate there)
+  // (its LDS-DMA is issued piecewise between the MFMA groups -- compute_staging -- which is worth +5..8 % on this 8-wave
+  //  tile: 193 -> 176 us on the 64x64 C320 conv, 965 -> 1020 TF/s on the big one; the 4-wave tiles lose 10..20 % with it and
+  //  the 256x320 tile has no registers left for it)
   if (force == 1 || (force == 0 && big))
-    return launch<T, 256, 128, 4, 2, 3, TRANS>(a, M, Ho, Wo, st);
+    return launch<T, 256, 128, 4, 2, 3, TRANS, 128, true>(a, M, Ho, Wo, st);
   // (a 128x160 tile for N = 320 measured slower than five 64-wide tiles on MI355X: 487 vs 612 TF/s on the 3x3 conv)
   // (1x1 layers with few 128x128 tiles run faster on 128x64: three co-resident workgroups per CU hide the short K loop's
   //  ramp; 26.8 vs 31.3 us at M4096 K1280 N1280, 30.8 vs 36.0 at M16384 K640 N640 -- what the per-shape tuner picks too)
