@@ -70,7 +70,7 @@ typedef struct {
   int64_t workspace_bytes;
   int32_t tile;           /* 0 = library heuristic; 1 = 256x128 (8 waves, 3-stage), 2 = 128x128, 3 = 128x64, 4 = 64x64,
                              5 = 256x320 (fp16, N % 320 == 0; 2 LDS stages of 128-byte K-steps), 6 = 256x320 with a 4-deep ring of
-                             64-byte K-steps.  Set by the host-side per-shape tuner (ops.tune_igemm)  */
+                             64-byte K-steps, 7 = 128x320 (8 waves, for half as many pixels).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
   int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split                      */
 } sr_igemm_args;
 int sr_igemm(const sr_igemm_args* args, void* stream);

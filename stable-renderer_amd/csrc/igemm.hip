@@ -585,8 +585,14 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // activation tile is fetched once for N = 320, and 142 FLOP per byte staged through the 64 B/clk TCP->LDS path (a
     // 128x128 tile: 64 FLOP/B = exactly the MFMA rate, so that path saturates first).  Needs a full round of workgroups:
     // measured 830 vs 627 TF/s on the 64x64 C320 3x3 conv, 1086 vs 1000 on C1280, but 556 vs 678 at 32x32 C640.
-    if ((force == 5 || force == 6) && a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d (256x320) needs N %% 320 == 0, N=%d", force, a.N);
+    if ((force >= 5 && force <= 7) && a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d (256x320) needs N %% 320 == 0, N=%d", force, a.N);
     if (force == 6) return launch<T, 256, 320, 4, 2, 4, TRANS, 64>(a, M, Ho, Wo, st);
+    // 128x320 (8 waves as 2x4, 64x80 per wave, 112 KB): the same full-width rows for layers with half as many pixels -- the
+    // 32x32 level (M = 16384, N = 640) gets exactly one round of 256 workgroups: 130 vs 161 us on its 3x3 conv (926 TF/s),
+    // 61 vs 80 us on the K = 2560 linear.  (A 64x320 tile for the 16x16 level measured no better than split-K 128x128.)
+    if (force == 7 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) < 256 &&
+                       (int64_t)((M + 127) / 128) * (a.N / 320) >= 256))
+      return launch<T, 128, 320, 2, 4, 2, TRANS>(a, M, Ho, Wo, st);
     // (a 256x160 tile with FOUR waves of 128x80 and 64-byte K-steps -- 53 KB, two workgroups per CU so that one's epilogue
     //  overlaps the other's main loop -- measured 636 vs 1100 TF/s on the big conv and 431 vs 273 us on the 64x64 GEGLU layer)
 
@@ -641,7 +647,7 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->upsample && a->stride != 1) SR_FAIL(SR_ERR_INVALID, "sr_igemm: upsample with stride");
   if (a->N <= 0 || a->B <= 0 || a->H <= 0 || a->W <= 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad sizes");
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
-  if (a->tile < 0 || a->tile > 6 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
+  if (a->tile < 0 || a->tile > 7 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }
   else if (a->stride == 2) { Ho = (a->H + 2 * (a->KH / 2) - a->KH) / 2 + 1; Wo = (a->W + 2 * (a->KH / 2) - a->KH) / 2 + 1; }
