@@ -109,6 +109,9 @@ class PlanBuilder:
     # ---- ops ------------------------------------------------------------------------------------------
     def igemm(self, a, w, out, B, H, W, C1, N, **kw):
         self.hold(a, w, out, kw.get("a2"), kw.get("bias"), kw.get("rowvec"), kw.get("residual"))
+        if (kw.get("KH", 1) == 1 and kw.get("stride", 1) == 1 and not kw.get("upsample", 0) and kw.get("rowvec") is None
+                and not kw.get("transpose_out", 0)):
+            B, H, W = B * H * W, 1, 1          # a 1x1 convolution IS the linear layer over all pixels: no per-row (b, y, x) split
         ar = O.igemm_args(a, w, out, B, H, W, C1, N, dtype=self.dtype, **kw)
         if self._lane == 1:
             ar.split = -1                      # the split-K workspace belongs to the main lane
