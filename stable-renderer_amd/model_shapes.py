@@ -115,3 +115,31 @@ def vae_decoder_names_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_c
     out += [("norm_out.weight", (c0,)), ("norm_out.bias", (c0,)), ("conv_out.weight", (out_ch, c0, 3, 3)), ("conv_out.bias", (out_ch,))]
     norms.append("norm_out.weight")
     return out, norms
+
+
+def controlnet_names_shapes(cfg, hint_channels=3):
+    """cldm.ControlNet state-dict names/shapes (comfy/cldm/cldm.py:30-282) for a UNet config: the UNet's time embedding,
+    encoder and middle block, the 8-conv hint encoder (16,16,32,32,96,96,256 -> model_channels), one 1x1 zero conv per
+    encoder output and middle_block_out."""
+    ns, norms = unet_names_shapes(cfg)
+    keep = ("time_embed.", "input_blocks.", "middle_block.")
+    out = [(n, sh) for n, sh in ns if n.startswith(keep)]
+    norm_out = [n for n in norms if n.startswith(keep)]
+    mc = cfg["model_channels"]
+    chans = [(0, hint_channels, 16), (2, 16, 16), (4, 16, 32), (6, 32, 32), (8, 32, 96), (10, 96, 96), (12, 96, 256), (14, 256, mc)]
+    for i, cin, cout in chans:
+        out += [(f"input_hint_block.{i}.weight", (cout, cin, 3, 3)), (f"input_hint_block.{i}.bias", (cout,))]
+    # zero convs: one per encoder feature (conv_in, every res block, every downsample)
+    zc = [mc]
+    ch = mc
+    nlev = len(cfg["channel_mult"])
+    for lev in range(nlev):
+        for _ in range(cfg["num_res_blocks"][lev]):
+            ch = mc * cfg["channel_mult"][lev]
+            zc.append(ch)
+        if lev != nlev - 1:
+            zc.append(ch)
+    for i, c in enumerate(zc):
+        out += [(f"zero_convs.{i}.0.weight", (c, c, 1, 1)), (f"zero_convs.{i}.0.bias", (c,))]
+    out += [("middle_block_out.0.weight", (ch, ch, 1, 1)), ("middle_block_out.0.bias", (ch,))]
+    return out, norm_out

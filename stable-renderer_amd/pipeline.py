@@ -50,13 +50,19 @@ class BakeBallScene:
 
 class FramePipeline:
     def __init__(self, unet, vae, scene, n_views=8, steps=20, cfg=8.0, sampler="ddim", scheduler="normal",
-                 corresponder=None, use_graph=True, bg_seed=1, shard=None):
+                 corresponder=None, use_graph=True, bg_seed=1, shard=None, controls=None):
         """shard: optional parallel.ViewShard over the ``n_views`` of ONE overlapped group (one process per GPU): this process
         then rasterises / diffuses / decodes only its own views; id maps are all-gathered once per call, latents once per
         overlap step, the injected frame's tokens are broadcast per transformer block and decoded frames go to rank 0 for
         the ordered corr-map update.  Without it the pipeline is a self-contained replica."""
         self.unet, self.vae, self.scene = unet, vae, scene
+        # controls: [("depth" | "normal" | "color" | "canny", ControlNet)] -- ControlNets driven by the G-buffer planes of the
+        # same views, as the reference's miku-control workflow (depth + normalbae; EngineData.depth_maps / normal_maps ->
+        # ControlNetApply)
+        self.controls = list(controls or [])
         self.shard = shard if (shard is not None and shard.world > 1) else None
+        if self.controls and self.shard is not None:
+            raise NotImplementedError("ControlNets with a view-sharded group")
         self.N_all = n_views
         n_views = n_views if self.shard is None else self.shard.n_local
         self.N, self.steps, self.cfg, self.sampler, self.scheduler = n_views, steps, cfg, sampler, scheduler
@@ -70,7 +76,8 @@ class FramePipeline:
         # ignore_obj_mat_id_when_update=True is the reference option that avoids _update's double-gather IndexError on
         # partially covered frames (corrmap.py:703/710; reproduced in corrmap.py of this package)
         self.baker = DefaultCorresponder(update_corrmap_mode="first", ignore_obj_mat_id_when_update=True)
-        self.runner = DiffusionRunner(unet, n_views, self.h, self.w, cfg, use_graph=use_graph, shard=self.shard)
+        self.runner = DiffusionRunner(unet, n_views, self.h, self.w, cfg, use_graph=use_graph, shard=self.shard,
+                                      controlnets=[c for _, c in self.controls])
         self.vplan = vae.build(n_views, self.h, self.w)
         g = torch.Generator().manual_seed(bg_seed)
         self.bg_noise = torch.randn(1, self.H, self.W, 4, generator=g).to(dev)                # RenderManager.GlobalBGNoise
@@ -79,6 +86,8 @@ class FramePipeline:
         self.colors = torch.zeros(n_views, self.H, self.W, 3, dtype=torch.float16, device=dev)
         self.masks = torch.zeros(n_views, self.H, self.W, dtype=torch.float16, device=dev)
         self.noise = torch.zeros(n_views, 4, self.h, self.w, dtype=torch.float32, device=dev)
+        self.normal_depth = torch.zeros(n_views, self.H, self.W, 4, dtype=torch.float16, device=dev) if self.controls else None
+        self.canny = torch.zeros(n_views, self.H, self.W, 3, dtype=torch.float32, device=dev) if self.controls else None
         self.frame0 = 0
 
     def set_prompt(self, positive, negative):
@@ -93,6 +102,9 @@ class FramePipeline:
             self.colors[i].copy_(self.gbuf.color[..., :3])
             alpha = self.gbuf.color[..., 3].contiguous()
             self.masks[i].copy_(1.0 - alpha)
+            if self.controls:
+                self.normal_depth[i].copy_(self.gbuf.normal_depth)
+                self.canny[i].copy_(self.gbuf.canny)
             _, nz = O.noise_pool(self.gbuf.noise.unsqueeze(0), alpha.unsqueeze(0), self.bg_noise)
             self.noise[i].copy_(nz[0])
         self.frame0 += self.N_all
@@ -122,6 +134,10 @@ class FramePipeline:
                     if ctx.timestep < corr.step_finished_stop_inject_timestep:
                         return
                     self.shard.overlap_step(ctx.noise, lambda full: idx_all.step(full, corr.step_finished_inject_ratio))
+        if self.controls:
+            planes = {"depth": lambda: self.normal_depth[..., 3:4].expand(-1, -1, -1, 3), "normal": lambda: self.normal_depth[..., :3],
+                      "color": lambda: self.colors, "canny": lambda: self.canny}
+            self.runner.set_control_hints([planes[k]().permute(0, 3, 1, 2).float().contiguous() for k, _ in self.controls])
         samples, inj = self.runner.sample(ed.noise_maps["noise"], self.steps, self.sampler, self.scheduler,
                                           latent_image=ed.noise_maps["samples"], inject_n_rand=n_rand, step_callback=cb)
         if isinstance(corr, OverlapCorresponder) and inj is not None:
@@ -162,7 +178,7 @@ class FramePipeline:
 
 
 def build_sd15_pipeline(dtype=torch.float16, n_views=8, steps=20, cfg=8.0, W=512, H=512, seed=0, unet_cfg=None,
-                        use_graph=True, vae_ch=128, device="cuda", shard=None):
+                        use_graph=True, vae_ch=128, device="cuda", shard=None, controls=None):
     """Random-init SD1.5-shaped UNet + VAE decoder (no checkpoints offline; synth.py) on the bake_ball scene."""
     from . import synth
     from .unet import UNet, SD15_CFG
@@ -174,7 +190,14 @@ def build_sd15_pipeline(dtype=torch.float16, n_views=8, steps=20, cfg=8.0, W=512
     vns, vnorms = vae_decoder_names_shapes(ch=vae_ch)
     vae = VAEDecoder(synth.synth_state_dict(vns, seed=seed + 2, norm_names=vnorms), dtype=dtype, device=device)
     scene = BakeBallScene(W, H, device=device)
-    pipe = FramePipeline(unet, vae, scene, n_views=n_views, steps=steps, cfg=cfg, use_graph=use_graph, shard=shard)
+    cns = []
+    for i, (kind, strength) in enumerate(controls or []):       # e.g. [("depth", 1.0), ("normal", 1.0)]: miku-control.json's pair
+        from .controlnet import ControlNet
+        from .model_shapes import controlnet_names_shapes
+        cns_, cnorms = controlnet_names_shapes(cfgu)
+        cns.append((kind, ControlNet(synth.synth_state_dict(cns_, seed=seed + 20 + i, norm_names=cnorms), cfgu, dtype=dtype,
+                                     device=device, strength=strength)))
+    pipe = FramePipeline(unet, vae, scene, n_views=n_views, steps=steps, cfg=cfg, use_graph=use_graph, shard=shard, controls=cns)
     g = torch.Generator().manual_seed(seed + 11)
     cd = cfgu["context_dim"]
     pipe.set_prompt(torch.randn(1, 77, cd, generator=g), torch.randn(1, 77, cd, generator=g))

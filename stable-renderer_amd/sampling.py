@@ -111,13 +111,17 @@ class DiffusionRunner:
     ``sample()`` is the body of custom_ksampler -> comfy.sample.sample -> KSampler.sample -> sampler loop with the
     model call replaced by the native plan; the latent stays resident in HBM for the whole run."""
 
-    def __init__(self, unet, N, h, w, cfg_scale, n_ctx=77, use_graph=True, shard=None):
+    def __init__(self, unet, N, h, w, cfg_scale, n_ctx=77, use_graph=True, shard=None, controlnets=None):
         """shard: optional parallel.ViewShard — this process then holds ``shard.n_local`` of the ``shard.n_views`` views of ONE
         overlapped group; N must equal shard.n_local."""
         self.shard = shard
         if shard is not None and shard.world > 1:
             assert N == shard.n_local
         self.unet, self.N, self.h, self.w = unet, N, h, w
+        # ControlNets (comfy/controlnet.py:180-214 get_control, chained through previous_controlnet: residuals are summed,
+        # control_merge :60-100); their plans read the UNet plan's own x / t / ctx buffers
+        self.controlnets = list(controlnets or [])
+        self._hints = None
         self.cfg_scale = float(cfg_scale)
         self.copies = 1 if math.isclose(self.cfg_scale, 1.0) else 2     # samplers.py:335 (skip uncond at cfg 1)
         self.n_ctx = n_ctx
@@ -136,8 +140,38 @@ class DiffusionRunner:
         key = None if inject_idx is None else len(inject_idx)
         sharded = self.shard is not None and self.shard.world > 1
         if self._plan is None or self._inject != key:
+            control, inputs, cn = None, None, None
+            if self.controlnets:
+                from .plan import PlanBuilder
+                B = self.N * self.copies
+                cfgu = self.unet.cfg
+                pb = PlanBuilder(self.unet.device, self.unet.dtype)
+                inputs = (pb.buf(B, cfgu["in_channels"], self.h, self.w, dtype=torch.float32, zero=True),
+                          pb.buf(B, dtype=torch.float32, zero=True), pb.buf(B, self.n_ctx, cfgu["context_dim"], zero=True))
+                cps = [c.build(B, self.h, self.w, *inputs, n_ctx=self.n_ctx) for c in self.controlnets]
+                outs, mid = list(cps[0]["output"]), cps[0]["middle"]
+                for cp in cps[1:]:                          # control_merge: element-wise sums of the residual lists
+                    merged = []
+                    for a, b in zip(outs, cp["output"]):
+                        if a is None or b is None:
+                            merged.append(a if b is None else b)
+                        else:
+                            y = pb.buf(*a.shape)
+                            pb.add(a, b, y)
+                            merged.append(y)
+                    outs = merged
+                    if mid is not None and cp["middle"] is not None:
+                        m2 = pb.buf(*mid.shape)
+                        pb.add(mid, cp["middle"], m2)
+                        mid = m2
+                    elif mid is None:
+                        mid = cp["middle"]
+                control = dict(output=outs, middle=mid)
+                cn = dict(plans=cps, merge=pb.take())
             self._plan = self.unet.build(self.N * self.copies, self.h, self.w, inject_idx=inject_idx, n_ctx=self.n_ctx,
-                                         inject_external=sharded and inject_idx is not None)
+                                         inject_external=sharded and inject_idx is not None, control=control, inputs=inputs)
+            self._plan["cn"] = cn
+            self._hints_loaded = False
             self._inject = key
             self._captured = False
         if inject_idx is not None and not sharded:
@@ -146,6 +180,14 @@ class DiffusionRunner:
             self._plan["inject"].copy_(torch.tensor([int(i) for i in inject_idx], dtype=torch.int32))
         self._inject_global = inject_idx
         return self._plan
+
+    def set_control_hints(self, hints):
+        """hints: one (N,3,8h,8w) tensor in [0,1] per ControlNet (ControlNetApply's image.movedim(-1,1), nodes.py:745-760);
+        the same hint serves the cond and uncond halves of the batch"""
+        if len(hints) != len(self.controlnets):
+            raise ValueError(f"{len(self.controlnets)} ControlNets need as many hints, got {len(hints)}")
+        self._hints = list(hints)
+        self._hints_loaded = False
 
     def set_conditioning(self, positive, negative):
         """positive / negative: (1 | N, n_ctx, ctx_dim) text embeddings (CONDRegular.process_cond repeats a single
@@ -163,6 +205,15 @@ class DiffusionRunner:
         else:
             p["ctx"].copy_(pos)
         p["prologue"].run()
+        if p.get("cn") is not None:
+            if self._hints is None:
+                raise ValueError("ControlNets are attached: call set_control_hints() before sampling")
+            for cp, hint in zip(p["cn"]["plans"], self._hints):
+                hb = cp["hint"]
+                hv = hint.to(hb.device, torch.float32)
+                for c in range(self.copies):
+                    hb[c * N:(c + 1) * N].copy_(hv.expand(N, -1, -1, -1) if hv.shape[0] == 1 else hv)
+                cp["prologue"].run()                        # hint encoder: once per run
 
     def model_eps(self, p, sigma, timestep_index):
         """calc_cond_uncond_batch + apply_model: xin = x/sqrt(sigma^2+1) for both chunks, t = argmin|log sigma|"""
@@ -183,6 +234,10 @@ class DiffusionRunner:
                             src[j].copy_(ln[li])
                         PAR.broadcast(src[j], owner, self.shard.group)
             return p["out"]
+        if p.get("cn") is not None:                         # ControlNet encoders on the same (x, t, ctx), then their merge
+            for cp in p["cn"]["plans"]:
+                cp["step"].run()
+            p["cn"]["merge"].run()
         if self.use_graph:
             if not self._captured:
                 torch.cuda.current_stream().synchronize()

@@ -205,7 +205,7 @@ class UNet:
         self.w, self.shapes = pack_weights(state_dict, dtype, self.device, pad_cin=("input_blocks.0.0",))
 
     # ------------------------------------------------------------------------------------------------
-    def build(self, B, h, w, inject_idx=None, n_ctx=77, control=None, inject_external=False):
+    def build(self, B, h, w, inject_idx=None, n_ctx=77, control=None, inject_external=False, inputs=None):
         """-> dict(prologue=Plan, step=Plan, x=(B,4,h,w) fp32 input buffer, t=(B,) fp32, ctx=(B,n_ctx,ctx_dim),
         out=(B,4,h,w) fp32, inject=(n_rand,) int32 device tensor or None).  inject_idx: list of batch indices whose
         post-LayerNorm tokens every batch entry attends to in self-attention (OverlapCorresponder.pre_atten_inject) or
@@ -218,9 +218,13 @@ class UNet:
         pro = PlanBuilder(dev, dt)                     # prompt-only work (cross-attention K/V)
         W = self.w
         mc, heads = cfg["model_channels"], cfg["num_heads"]
-        x_in = pb.buf(B, cfg["in_channels"], h, w, dtype=torch.float32, zero=True)
-        t_in = pb.buf(B, dtype=torch.float32, zero=True)
-        ctx = pb.buf(B, n_ctx, cfg["context_dim"], zero=True)
+        if inputs is not None:                         # (x, t, ctx) buffers shared with ControlNet plans built on them
+            x_in, t_in, ctx = inputs
+            pb.hold(x_in, t_in, ctx)
+        else:
+            x_in = pb.buf(B, cfg["in_channels"], h, w, dtype=torch.float32, zero=True)
+            t_in = pb.buf(B, dtype=torch.float32, zero=True)
+            ctx = pb.buf(B, n_ctx, cfg["context_dim"], zero=True)
         ldt_ctx = _cdiv(n_ctx, 8) * 8
         sel = None
         if inject_idx is not None:

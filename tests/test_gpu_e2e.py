@@ -144,3 +144,82 @@ def test_legacy_overlap_vs_reference():
     # alpha == 0 returns the input list untouched (overlap.py:203-204)
     z = LO.ResizeOverlap(LO.Scheduler(interpolate_begin=0.0), LO.Scheduler(), LO.AverageDistance())
     assert z(lat, cm, step=1, timestep=500) is lat
+
+
+def test_sampling_with_two_controlnets_vs_oracle():
+    """config-4 shape of the path: two ControlNets (depth + normal style hints, different strengths) chained as
+    control_merge does, inside the device sampling loop, vs the oracle composition controlnet_forward x2 -> summed residuals
+    -> unet_forward(control=...) under the same euler loop and CFG (each piece pinned to the reference by its own golden)."""
+    import sr_oracle as ORC
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    from stable_renderer_amd.controlnet import ControlNet
+    from stable_renderer_amd.sampling import DiffusionRunner
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    sd_u = _sd("unet_tiny_keys.json", 1)
+    sd_c1, sd_c2 = _sd("controlnet_tiny_keys.json", 5), _sd("controlnet_tiny_keys.json", 6)
+    g = torch.Generator().manual_seed(8)
+    N, h, w, steps, cfg_scale = 2, 16, 16, 3, 3.0
+    noise = torch.randn(N, 4, h, w, generator=g)
+    pos, neg = torch.randn(1, 77, 64, generator=g), torch.randn(1, 77, 64, generator=g)
+    hints = [torch.rand(N, 3, 8 * h, 8 * w, generator=g), torch.rand(N, 3, 8 * h, 8 * w, generator=g)]
+    strengths = (0.8, 0.5)
+
+    # ---- oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ms = ORC.ModelSampling()
+    sig, _ = ORC.ksampler_sigmas(ms, "normal", steps, None)
+    x0 = noise * torch.sqrt(1.0 + sig[0] ** 2.0)
+
+    def denoise_fn(xx, sigma):
+        xin, s2 = torch.cat([xx, xx]), torch.cat([sigma, sigma])
+        c = torch.cat([neg.expand(N, -1, -1), pos.expand(N, -1, -1)])
+        t = ms.timestep(s2).float()
+        xc = ORC.eps_input(xin, s2)
+        ctrls = [ORC.controlnet_forward(sd, cfg, xc, torch.cat([hh, hh]), t, c, strength=st)
+                 for sd, hh, st in zip((sd_c1, sd_c2), hints, strengths)]
+        merged = {"output": [a + b for a, b in zip(ctrls[0]["output"], ctrls[1]["output"])],
+                  "middle": [ctrls[0]["middle"][0] + ctrls[1]["middle"][0]]}
+        out = ORC.unet_forward(sd_u, cfg, xc, t, c, control=merged)
+        den = ORC.eps_denoised(xin, out, s2)
+        return den[:N] + (den[N:] - den[:N]) * cfg_scale
+    ref = ORC.sample_loop(denoise_fn, x0.clone(), sig, "euler", None) / 0.18215
+
+    # ---- HIP path
+    net = UNet(sd_u, cfg, dtype=torch.float32)
+    cns = [ControlNet(sd_c1, cfg, dtype=torch.float32, strength=strengths[0]), ControlNet(sd_c2, cfg, dtype=torch.float32, strength=strengths[1])]
+    for use_graph in (False, True):
+        run = DiffusionRunner(net, N, h, w, cfg_scale, use_graph=use_graph, controlnets=cns)
+        run.set_conditioning(pos, neg)
+        with pytest.raises(ValueError):
+            run.sample(noise, steps, "euler", "normal", seed=0)          # hints not set
+        run.set_control_hints(hints)
+        out, _ = run.sample(noise, steps, "euler", "normal", seed=0)
+        torch.cuda.synchronize()
+        err = (out.cpu() - ref).abs().max().item()
+        assert err < 2e-3 * max(1.0, ref.abs().max().item()), (use_graph, err)
+    # and the control really matters
+    plain = DiffusionRunner(net, N, h, w, cfg_scale, use_graph=False)
+    plain.set_conditioning(pos, neg)
+    o2, _ = plain.sample(noise, steps, "euler", "normal", seed=0)
+    assert (o2.cpu() - ref).abs().max().item() > 1e-2
+
+
+def test_pipeline_with_gbuffer_driven_controlnets():
+    """config 4 wiring: depth + normal ControlNets fed by the G-buffer planes of the same views (reference
+    resources/example-workflows/miku-control.json: EngineData.depth_maps / normal_maps -> ControlNetApply x2)"""
+    from stable_renderer_amd.pipeline import build_sd15_pipeline
+    from stable_renderer_amd.unet import SD15_CFG
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    kw = dict(dtype=torch.float32, n_views=2, steps=2, cfg=3.0, W=128, H=128, unet_cfg=cfg, use_graph=False, vae_ch=32)
+    torch.manual_seed(3)
+    base = build_sd15_pipeline(**kw).call().clone()
+    torch.manual_seed(3)
+    pipe = build_sd15_pipeline(controls=[("depth", 1.0), ("normal", 0.7)], **kw)
+    img = pipe.call().clone()
+    torch.cuda.synchronize()
+    assert img.shape == (2, 128, 128, 3) and bool(torch.isfinite(img).all())
+    hints = pipe.runner._hints
+    assert len(hints) == 2 and hints[0].shape == (2, 3, 128, 128)
+    assert float(hints[0].max()) > 0.0 and float((hints[0][:, 0] - hints[0][:, 1]).abs().max()) == 0.0   # depth repeated to 3 channels
+    assert float((img - base).abs().max()) > 1e-4            # the residuals reach the UNet
+    assert int(pipe.scene.corrmap._writtens.sum()) > 0
