@@ -174,7 +174,7 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
 // BKB = bytes of K per LDS stage: 128 (two MFMA k-substeps, 8 rows x 8 chunks per LDS-DMA instruction) or 64 (one k-substep,
 // 16 rows x 4 chunks) -- the 64-byte form halves a stage so that the 256x320 tile gets a FOUR-deep ring in 144 KB (three
 // K-steps of loads in flight instead of one: that tile is otherwise bound by the exposed load latency of every K-step).
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, bool SPREAD = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
                                                                         const int NT, const int nwg, const int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -294,11 +294,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
 #pragma unroll
     for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int j0 = 0, int j1 = BKB / 64) {
     const char* tP = smem + buf * STAGE_BYTES + pm0 * BKB;
     const char* tQ = smem + buf * STAGE_BYTES + BM * BKB + qn0 * BKB;
 #pragma unroll
-    for (int j = 0; j < BKB / 64; ++j) {
+    for (int j = j0; j < j1; ++j) {
       uint4 xf[TM], wf[TN];
 #pragma unroll
       for (int t = 0; t < TM; ++t) xf[t] = *(const uint4*)(tP + t * FBLK + foff[j]);
@@ -381,9 +381,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
       else if (D == 3 && younger == 1)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
       else                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // stage kt visible to all; everyone finished step kt-1
-      if constexpr (SPREAD) {
+      if constexpr (SPREAD == 1) {
         if (kt + D < nk) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; compute_staging(cur, nb); }
         else compute(cur);
+      } else if constexpr (SPREAD == 2 && BKB == 128) {
+        // the matrix pipe gets the first k-substep right after the barrier; the LDS-DMA burst (~150 scalar / address
+        // instructions for 9 pieces) is issued in its shadow
+        compute(cur, 0, 1);
+        if (kt + D < nk) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; stage(nb); }
+        compute(cur, 1, 2);
       } else {
         if (kt + D < nk) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; stage(nb); }
         compute(cur);
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, bool SPREAD = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, int SPREAD = 0>
 int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int Npad = (a.N + 127) / 128 * 128;
   const int MT = (M + BM - 1) / BM, NT = Npad / BN;
@@ -596,8 +602,11 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // (a 256x160 tile with FOUR waves of 128x80 and 64-byte K-steps -- 53 KB, two workgroups per CU so that one's epilogue
     //  overlaps the other's main loop -- measured 636 vs 1100 TF/s on the big conv and 431 vs 273 us on the 64x64 GEGLU layer)
 
+    // (LDS-DMA burst issued between the two k-substeps -- SPREAD 2 -- so the matrix pipe has work right after the barrier:
+    //  +3..9 %, 134 -> 125 us on the 64x64 C320 conv, 1200 -> 1286 TF/s on the big one, 252 -> 236 us on the 64x64 GEGLU;
+    //  the 128x320 tile is indifferent to it and the 4-wave tiles lose 5..10 %)
     if (force == 5 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) >= 256))
-      return launch<T, 256, 320, 4, 2, 2, TRANS>(a, M, Ho, Wo, st);
+      return launch<T, 256, 320, 4, 2, 2, TRANS, 128, 2>(a, M, Ho, Wo, st);
   } else {
     if (force >= 5) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d is fp16, non-transposed only", force);
   }
@@ -624,7 +633,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   //  tile: 193 -> 176 us on the 64x64 C320 conv, 965 -> 1020 TF/s on the big one; the 4-wave tiles lose 10..20 % with it and
   //  the 256x320 tile has no registers left for it)
   if (force == 1 || (force == 0 && big))
-    return launch<T, 256, 128, 4, 2, 3, TRANS, 128, true>(a, M, Ho, Wo, st);
+    return launch<T, 256, 128, 4, 2, 3, TRANS, 128, 1>(a, M, Ho, Wo, st);
   // (a 128x160 tile for N = 320 measured slower than five 64-wide tiles on MI355X: 487 vs 612 TF/s on the 3x3 conv)
   // (1x1 layers with few 128x128 tiles run faster on 128x64: three co-resident workgroups per CU hide the short K loop's
   //  ramp; 26.8 vs 31.3 us at M4096 K1280 N1280, 30.8 vs 36.0 at M16384 K640 N640 -- what the per-shape tuner picks too)
