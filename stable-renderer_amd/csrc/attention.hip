@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
 
   // K / V^T tiles: global -> registers one tile AHEAD of use, registers -> LDS (double buffered) after the barrier, so
   // the HBM/L2 latency of tile t+2 hides under the MFMA + softmax work of tile t and there is ONE barrier per tile.
-  constexpr int KPT = (KV_TILE * NCH + 255) / 256, VPT = (DT * 16 * VCH + 255) / 256;
+  constexpr int KPT = (KV_TILE * NCH + NTHR - 1) / NTHR, VPT = (DT * 16 * VCH + NTHR - 1) / NTHR;
   uint4 rk[KPT], rv[VPT];
   auto gload = [&](int k0) {
 #pragma unroll
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
 // S lives in two register sets that swap roles every tile (loop unrolled by two); K/V tiles go through a 3-slot LDS ring
 // (tile t+2 is written while t and t+1 are read) with ONE barrier per tile; global loads run one more tile ahead in
 // registers.  The interleave itself is requested with sched_group_barrier (1 MFMA : n VALU).
-template <int DQ, int DT, bool SR, int MB>
-__global__ __launch_bounds__(256, MB) void attn_pipe_kernel(const sr_attention_args p) {
+template <int DQ, int DT, bool SR, int MB, int NTHR = 256>
+__global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_args p) {
   using T = _Float16;
   constexpr int EPC = 8, QT = 2;
   constexpr int NCH = 4 * DQ, KROW = NCH * 16, VROW = KV_TILE * 2 + 8, VCH = KV_TILE * 2 / 16;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, MB) void attn_pipe_kernel(const sr_attention_a
   const int b = blockIdx.z, h = blockIdx.y;
   const int bk = p.Bk == 1 ? 0 : b;
   const int d = p.d, Tk = p.Tk;
-  const int q0 = blockIdx.x * (64 * QT) + wv * (16 * QT);
+  const int q0 = blockIdx.x * ((NTHR / 64) * 16 * QT) + wv * (16 * QT);
   const int NT = (Tk + KV_TILE - 1) / KV_TILE;
 
   uint4 qf[QT][DQ];
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, MB) void attn_pipe_kernel(const sr_attention_a
   int k_key[KPT], k_lds[KPT], k_el[KPT]; bool k_ok[KPT];
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
-    const int idx = tid + i * 256, key = idx / NCH, ch = idx - key * NCH;
+    const int idx = tid + i * NTHR, key = idx / NCH, ch = idx - key * NCH;
     k_key[i] = key; k_el[i] = ch * EPC;
     k_ok[i] = idx < KV_TILE * NCH && ch * EPC < d;
     k_lds[i] = idx < KV_TILE * NCH ? key * KROW + ((NCH == 8) ? (ch ^ (key & 7)) : ch) * 16 : -1;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, MB) void attn_pipe_kernel(const sr_attention_a
   const T* v_src[VPT]; int v_lds[VPT], v_k8[VPT]; bool v_ok[VPT], v_one[VPT];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int idx = tid + i * 256, row = idx / VCH, ch = idx - row * VCH;
+    const int idx = tid + i * NTHR, row = idx / VCH, ch = idx - row * VCH;
     v_ok[i] = idx < DT * 16 * VCH && row < d;
     v_one[i] = SR && row == d;
     v_lds[i] = idx < DT * 16 * VCH ? K_BYTES + row * VROW + ch * 16 : -1;
@@ -529,14 +529,14 @@ __global__ __launch_bounds__(256, MB) void attn_pipe_kernel(const sr_attention_a
   }
 }
 
-template <int DQ, int DT, bool SR, int MB = 2>
+template <int DQ, int DT, bool SR, int MB = 2, int NTHR = 256>
 int launch_pipe(const sr_attention_args& a, hipStream_t st) {
-  dim3 grid(sr_cdiv(a.Tq, 128), a.heads, a.B);
+  dim3 grid(sr_cdiv(a.Tq, (NTHR / 64) * 32), a.heads, a.B);
   constexpr int lds = 3 * (KV_TILE * 4 * DQ * 16 + DT * 16 * (KV_TILE * 2 + 8));
-  auto k = attn_pipe_kernel<DQ, DT, SR, MB>;
+  auto k = attn_pipe_kernel<DQ, DT, SR, MB, NTHR>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k, grid, dim3(NTHR), lds, st, a);
   SR_CHECK_LAUNCH("sr_attention");
   return SR_OK;
 }
