@@ -437,16 +437,21 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   auto pv = [&](const uint4 (&pf)[2][QT], int slot) {
     const char* cV = smem + slot * TILE_B + K_BYTES;
 #pragma unroll
-    for (int kp = 0; kp < 2; ++kp)
+    for (int kp = 0; kp < 2; ++kp) {
+      uint4 vf[DT];                                          // one burst of V^T fragment reads per key half, then the MFMAs
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const char* vr = cV + (dt * 16 + c16) * VROW + kp * 64 + g4 * 8;
         const uint2 lo = *(const uint2*)vr;
         const uint2 hi = *(const uint2*)(vr + 32);
-        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) sr_mma(o[dt][qt], vf, pf[kp][qt], T());
+        vf[dt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sr_mma(o[dt][qt], vf[dt], pf[kp][qt], T());
+    }
   };
 
   // ---- prologue: tiles 0..2 into the ring, tile 3 in registers, S(0) and its row max
