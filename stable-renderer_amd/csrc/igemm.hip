@@ -174,8 +174,8 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
 // BKB = bytes of K per LDS stage: 128 (two MFMA k-substeps, 8 rows x 8 chunks per LDS-DMA instruction) or 64 (one k-substep,
 // 16 rows x 4 chunks) -- the 64-byte form halves a stage so that the 256x320 tile gets a FOUR-deep ring in 144 KB (three
 // K-steps of loads in flight instead of one: that tile is otherwise bound by the exposed load latency of every K-step).
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
                                                                         const int NT, const int nwg, const int tile0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KE = BKB / (int)sizeof(T);            // elements of K per step
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const sr_
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, int SPREAD = 0>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, int SPREAD = 0, int MINB = 1>
 int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int Npad = (a.N + 127) / 128 * 128;
   const int MT = (M + BM - 1) / BM, NT = Npad / BN;
@@ -455,7 +455,7 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   constexpr int lds_epi_all = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);   // fp32 output sub-tiles of all waves
   constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
   constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB, SPREAD>;
+  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB, SPREAD, MINB>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   (void)NT;

@@ -31,7 +31,7 @@ shapes = [
     (65536, 1, 1, 320, 2560, 1, 0),
     (16, 8, 8, 1280, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 32, 32, 640, 640, 3, 0), (16, 64, 64, 320, 320, 3, 0),
 ]
-if len(sys.argv) > 1 and sys.argv[1] not in ("splitk", "t5", "t78"):
+if len(sys.argv) > 1 and sys.argv[1] not in ("splitk", "t5", "t78", "vae"):
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 if len(sys.argv) > 1 and sys.argv[1] == "t5":
     TILES = (0, 1, 2, 3, 5, 7)
@@ -46,6 +46,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "t78":
     shapes = [(16384, 1, 1, 640, 640, 1, 0), (4096, 1, 1, 1280, 1280, 1, 0), (4096, 1, 1, 5120, 1280, 1, 0), (16384, 1, 1, 2560, 640, 1, 0),
               (16, 32, 32, 640, 640, 3, 0), (16, 32, 32, 1280, 640, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 8, 8, 1280, 1280, 3, 0),
               (65536, 1, 1, 320, 320, 1, 0), (16384, 1, 1, 640, 5120, 1, 2), (4096, 1, 1, 1280, 10240, 1, 2)]
+if len(sys.argv) > 1 and sys.argv[1] == "vae":
+    TILES = (0, 1, 2, 8)
+    shapes = [(8, 512, 512, 128, 128, 3, 0), (8, 256, 256, 256, 256, 3, 0), (8, 128, 128, 512, 512, 3, 0), (8, 512, 512, 256, 128, 3, 0),
+              (16, 64, 64, 1280, 1280, 3, 0), (65536, 1, 1, 320, 2560, 1, 2)]
 if len(sys.argv) > 1 and sys.argv[1] == "splitk":
     os.environ.pop("SR_IGEMM_TILE", None)
     for sh in [(16, 8, 8, 1280, 1280, 3, 0), (16, 8, 8, 2560, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 16, 16, 2560, 1280, 3, 0),
