@@ -267,10 +267,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     auto gq = [&](int i) { return ((i * NW + wv) < GQ ? (i * NW + wv) : GQ - 1) * 1024; };
     {
       const unsigned lP = __builtin_amdgcn_readfirstlane(sr_lds_addr(tP)), lQ = __builtin_amdgcn_readfirstlane(sr_lds_addr(tQ));
+      const unsigned m0 = sr_m0_save();
 #pragma unroll
-      for (int i = 0; i < NIP; ++i) sr_glds16_asm((fromA ? rowA[i] : rowB[i]) + off, lP + gp(i));
+      for (int i = 0; i < NIP; ++i) sr_glds16_asm_nosave((fromA ? rowA[i] : rowB[i]) + off, lP + gp(i));
 #pragma unroll
-      for (int i = 0; i < NIQ; ++i) { sr_glds16_asm(wrow[i], lQ + gq(i)); wrow[i] += BKB; }
+      for (int i = 0; i < NIQ; ++i) { sr_glds16_asm_nosave(wrow[i], lQ + gq(i)); wrow[i] += BKB; }
+      sr_m0_restore(m0);
     }
     if (++s_kk == KPT) { s_kk = 0; if (++s_tap < ntaps) set_tap(s_tap); }
   };
@@ -327,14 +329,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     auto piece = [&](int i) {
       if (i < NIP) {
         const int g = ((i * NW + wv) < GP ? (i * NW + wv) : GP - 1) * 1024;
-        sr_glds16_asm((fromA ? rowA[i] : rowB[i]) + off, lP + g);
+        sr_glds16_asm_nosave((fromA ? rowA[i] : rowB[i]) + off, lP + g);
       } else if (i < PIECES) {
         const int q = i - NIP;
         const int g = ((q * NW + wv) < GQ ? (q * NW + wv) : GQ - 1) * 1024;
-        sr_glds16_asm(wrow[q], lQ + g);
+        sr_glds16_asm_nosave(wrow[q], lQ + g);
         wrow[q] += BKB;
       }
     };
+    const unsigned m0_keep = sr_m0_save();                   // (MFMA / ds_read between the pieces do not use M0)
 #pragma unroll
     for (int j = 0; j < BKB / 64; ++j) {
       uint4 xf[TM], wf[TN];
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
         }
       }
     }
+    sr_m0_restore(m0_keep);
     if (++s_kk == KPT) { s_kk = 0; if (++s_tap < ntaps) set_tap(s_tap); }
   };
   {

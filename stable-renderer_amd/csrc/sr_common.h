@@ -51,6 +51,17 @@ __device__ __forceinline__ void sr_glds16_asm(const void* gsrc, unsigned lds_add
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
+// burst form: M0 is saved once before and restored once after a run of LDS-DMA pieces (nothing between the pieces of a
+// burst touches M0: address selects and 64-bit adds only)
+__device__ __forceinline__ unsigned sr_m0_save() {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+  return keep;
+}
+__device__ __forceinline__ void sr_m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep)); }
+__device__ __forceinline__ void sr_glds16_asm_nosave(const void* gsrc, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory");
+}
 __device__ __forceinline__ unsigned sr_lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
