@@ -68,6 +68,12 @@ typedef struct {
                              output tiles to fill 256 CUs).  NULL = never split.  May be shared by all ops
                              of a stream; contents are dead after the call.                            */
   int64_t workspace_bytes;
+  const float* row_stats; /* optional [M, 2] fp32 (rstd, -rstd*mean) of the INPUT rows: LayerNorm folded into the GEMM --
+                             out = rstd[m] * (x[m,:] . W'[n,:]) + (-rstd[m]*mean[m]) * colsum[n] + bias'[n] with
+                             W' = W * gamma (per k), colsum[n] = sum_k W'[n,k], bias' = bias + W . beta: the GEMM reads
+                             the un-normalised rows and the normalised tensor is never materialised
+                             (BasicTransformerBlock norm1/2/3 -> to_q/k/v, ff.net.0, attention.py:521-654)          */
+  const float* colsum;    /* [N] fp32, required with row_stats                                                     */
   int32_t tile;           /* 0 = library heuristic; 1 = 256x128 (8 waves, 3-stage), 2 = 128x128, 3 = 128x64, 4 = 64x64,
                              5 = 256x320 (fp16, N % 320 == 0; 2 LDS stages of 128-byte K-steps), 6 = 256x320 with a 4-deep ring of
                              64-byte K-steps, 7 = 128x320 (8 waves, for half as many pixels).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
@@ -90,6 +96,9 @@ typedef struct {
 int sr_groupnorm(const sr_groupnorm_args* args, void* stream);
 int64_t sr_groupnorm_scratch_floats(int32_t B, int32_t HW);
 
+/* Per-row LayerNorm statistics for the folded form (sr_igemm_args.row_stats): stats[r] = (rstd, -rstd*mean), fp32,
+ * biased variance as torch.nn.LayerNorm. */
+int sr_row_stats(const void* x, float* stats, int32_t rows, int32_t C, float eps, int32_t dtype, void* stream);
 /* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3, attention.py:521,613,648). rows x C. */
 int sr_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t rows, int32_t C,
                  float eps, int32_t dtype, void* stream);
@@ -130,7 +139,8 @@ typedef enum {
   SR_OP_IGEMM = 1, SR_OP_GROUPNORM = 2, SR_OP_LAYERNORM = 3, SR_OP_ATTENTION = 4, SR_OP_NCHW_TO_NHWC = 5,
   SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9, SR_OP_GATHER_ROWS = 10, SR_OP_ADD_SCALED = 11,
   SR_OP_FORK = 12,   /* side lane may start: it waits for everything issued on the main lane so far                       */
-  SR_OP_JOIN = 13    /* main lane waits for everything issued on the side lane so far                                     */
+  SR_OP_JOIN = 13,   /* main lane waits for everything issued on the side lane so far                                     */
+  SR_OP_ROW_STATS = 14 /* sr_row_stats; uses the `ln` member: x, y = stats, rows, C, dtype, eps                           */
 } sr_op_kind;
 /* lane: 0 = the caller's stream, 1 = the executor's side stream.  Independent branches of the graph (a ResBlock's 1x1
  * skip convolution beside its GroupNorm/conv path; the injected frame's K/V projections beside the Q projection) are

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsr_hip.so")
 
 SR_F16, SR_F32 = 0, 1
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_TIMESTEP_EMBED, OP_SILU,
- OP_SOFTMAX_ROWS, OP_GATHER_ROWS, OP_ADD_SCALED, OP_FORK, OP_JOIN) = range(1, 14)
+ OP_SOFTMAX_ROWS, OP_GATHER_ROWS, OP_ADD_SCALED, OP_FORK, OP_JOIN, OP_ROW_STATS) = range(1, 15)
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -21,7 +21,7 @@ class IgemmArgs(C.Structure):
                 ("zero_page", vp), ("B", i32), ("H", i32), ("W", i32), ("C1", i32), ("C2", i32), ("N", i32),
                 ("KH", i32), ("stride", i32), ("upsample", i32), ("act", i32), ("transpose_out", i32), ("ldt", i32),
                 ("out_f32", i32), ("dtype", i32), ("scale", f32), ("rowvec_ld", i32), ("workspace", vp),
-                ("workspace_bytes", C.c_int64), ("tile", i32), ("split", i32)]
+                ("workspace_bytes", C.c_int64), ("row_stats", vp), ("colsum", vp), ("tile", i32), ("split", i32)]
 
 
 class GroupNormArgs(C.Structure):
@@ -93,6 +93,7 @@ SYMBOLS = {
     "sr_groupnorm": (C.c_int, [P(GroupNormArgs), vp]),
     "sr_groupnorm_scratch_floats": (i64, [i32, i32]),
     "sr_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i32, f32, i32, vp]),
+    "sr_row_stats": (C.c_int, [vp, vp, i32, i32, f32, i32, vp]),
     "sr_attention": (C.c_int, [P(AttentionArgs), vp]),
     "sr_nchw_to_nhwc": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, vp, i32, vp]),
     "sr_nhwc_to_nchw": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
 
   // K / V^T tiles: global -> registers one tile AHEAD of use, registers -> LDS (double buffered) after the barrier, so
   // the HBM/L2 latency of tile t+2 hides under the MFMA + softmax work of tile t and there is ONE barrier per tile.
-  constexpr int KPT = (KV_TILE * NCH + NTHR - 1) / NTHR, VPT = (DT * 16 * VCH + NTHR - 1) / NTHR;
+  constexpr int KPT = (KV_TILE * NCH + 255) / 256, VPT = (DT * 16 * VCH + 255) / 256;
   uint4 rk[KPT], rv[VPT];
   auto gload = [&](int k0) {
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   constexpr int EPC = 8, QT = 2;
   constexpr int NCH = 4 * DQ, KROW = NCH * 16, VROW = KV_TILE * 2 + 8, VCH = KV_TILE * 2 / 16;
   constexpr int K_BYTES = KV_TILE * KROW, V_BYTES = DT * 16 * VROW, TILE_B = K_BYTES + V_BYTES;
-  constexpr int KPT = (KV_TILE * NCH + 255) / 256, VPT = (DT * 16 * VCH + 255) / 256;
+  constexpr int KPT = (KV_TILE * NCH + NTHR - 1) / NTHR, VPT = (DT * 16 * VCH + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;

@@ -57,11 +57,18 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
       for (int tm = tm0; tm < tm0 + TMP; ++tm) {
         const int m = m0 + pm0 + tm * 16 + c16;
         const int b = (m < M) ? m / rpb : 0;
+        float2 rs = make_float2(1.f, 0.f);                   // folded LayerNorm: (rstd, -rstd*mean) of input row m
+        if (p.row_stats && m < M) rs = *(const float2*)(p.row_stats + 2 * (int64_t)m);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           const int n = n0 + qn0 + tn * 16 + 4 * g4;
           float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
           if (n < N) {                                       // N % 4 == 0 on this path
+            if (p.row_stats) {
+              const float4 cs = *(const float4*)(p.colsum + n);
+              v[0] = fmaf(rs.x, v[0], rs.y * cs.x); v[1] = fmaf(rs.x, v[1], rs.y * cs.y);
+              v[2] = fmaf(rs.x, v[2], rs.y * cs.z); v[3] = fmaf(rs.x, v[3], rs.y * cs.w);
+            }
             if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
             if (p.rowvec) { const float4 rv = *(const float4*)(p.rowvec + (int64_t)b * ldr + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
           }
@@ -129,6 +136,10 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
         if (n >= N) continue;
         float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
         const int nv = (N - n) < 4 ? (N - n) : 4;
+        if (p.row_stats) {
+          const float2 rs = *(const float2*)(p.row_stats + 2 * (int64_t)m);
+          for (int r = 0; r < nv; ++r) v[r] = fmaf(rs.x, v[r], rs.y * p.colsum[n + r]);
+        }
         if (p.bias) { for (int r = 0; r < nv; ++r) v[r] += p.bias[n + r]; }
         if (p.rowvec) { for (int r = 0; r < nv; ++r) v[r] += p.rowvec[(int64_t)b * ldr + n + r]; }
         if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
@@ -427,8 +438,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
         const int n = n0 + qn0 + tn * 16 + c16;
         if (n >= N) continue;
         const float bz = p.bias ? p.bias[n] : 0.f;
-        float v[4] = {acc[tm][tn][0] * scale + bz, acc[tm][tn][1] * scale + bz, acc[tm][tn][2] * scale + bz,
-                      acc[tm][tn][3] * scale + bz};
+        float v[4] = {acc[tm][tn][0] * scale, acc[tm][tn][1] * scale, acc[tm][tn][2] * scale, acc[tm][tn][3] * scale};
+        if (p.row_stats) {                                 // a lane holds 4 consecutive input rows of one output channel
+          const float cs = p.colsum[n];
+          for (int r = 0; r < 4; ++r)
+            if (m + r < M) { const float2 rs = *(const float2*)(p.row_stats + 2 * (int64_t)(m + r)); v[r] = fmaf(rs.x, v[r], rs.y * cs); }
+        }
+        for (int r = 0; r < 4; ++r) v[r] += bz;
         if (vec) {
           const int b = m / rpb, t = m - b * rpb;
           const int64_t oi = ((int64_t)b * N + n) * p.ldt + t;
@@ -499,6 +515,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sr_igemm_args 
   f32x4 acc = ws[0];
   for (int z = 1; z < S; ++z) acc += ws[z * zs];
   float v[4] = {acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale};
+  if (p.row_stats) {
+    const float2 rs = *(const float2*)(p.row_stats + 2 * (int64_t)m);
+    const float4 cs = *(const float4*)(p.colsum + n);
+    v[0] = fmaf(rs.x, v[0], rs.y * cs.x); v[1] = fmaf(rs.x, v[1], rs.y * cs.y);
+    v[2] = fmaf(rs.x, v[2], rs.y * cs.z); v[3] = fmaf(rs.x, v[3], rs.y * cs.w);
+  }
   if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
   if (p.rowvec) {
     const int ldr = p.rowvec_ld ? p.rowvec_ld : N;
@@ -660,6 +682,8 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->upsample && a->stride != 1) SR_FAIL(SR_ERR_INVALID, "sr_igemm: upsample with stride");
   if (a->N <= 0 || a->B <= 0 || a->H <= 0 || a->W <= 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad sizes");
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
+  if (a->row_stats && !a->colsum) SR_FAIL(SR_ERR_INVALID, "sr_igemm: row_stats without colsum");
+  if (a->row_stats && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
   if (a->tile < 0 || a->tile > 7 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }

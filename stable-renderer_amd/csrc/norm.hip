@@ -346,7 +346,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   }
 }
 
+// one wave per row: (rstd, -rstd*mean) for the LayerNorm folded into the consuming GEMM (sr_igemm_args.row_stats)
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int rows, int C, float eps) {
+  constexpr int EPC = sr_traits<T>::EPC;
+  constexpr int MAXC = 5;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int cpt = C / EPC;
+  float v[MAXC][EPC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cc = lane + i * 64;
+    if (cc < cpt) {
+      load_chunk<T>(x + (int64_t)row * C + cc * EPC, v[i]);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s += v[i][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cc = lane + i * 64;
+    if (cc < cpt) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if (lane == 0) {
+    const float rstd = rsqrtf(q / (float)C + eps);
+    *(float2*)(stats + 2 * (int64_t)row) = make_float2(rstd, -rstd * mean);
+  }
+}
+
 }  // namespace
+
+extern "C" int sr_row_stats(const void* x, float* stats, int32_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
+  if (!x || !stats) SR_FAIL(SR_ERR_INVALID, "sr_row_stats: null pointer");
+  const int epc = dtype == SR_F16 ? 8 : 4;
+  if (C % epc || C / epc > 64 * 5) SR_FAIL(SR_ERR_INVALID, "sr_row_stats: C=%d unsupported", C);
+  hipStream_t st = sr_stream(stream);
+  dim3 grid(sr_cdiv(rows, 4));
+  if (dtype == SR_F16) hipLaunchKernelGGL(row_stats_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)x, stats, rows, C, eps);
+  else if (dtype == SR_F32) hipLaunchKernelGGL(row_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, rows, C, eps);
+  else SR_FAIL(SR_ERR_INVALID, "sr_row_stats: dtype");
+  SR_CHECK_LAUNCH("sr_row_stats");
+  return SR_OK;
+}
 
 extern "C" int64_t sr_groupnorm_scratch_floats(int32_t B, int32_t HW) {
   return (int64_t)B * sr_cdiv(HW, gn_ppc(HW)) * 64 * 2;

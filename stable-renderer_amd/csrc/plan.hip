@@ -11,6 +11,8 @@ static int run_op(const sr_op& op, void* stream) {
     case SR_OP_ATTENTION: return sr_attention(&op.u.attn, stream);
     case SR_OP_LAYERNORM:
       return sr_layernorm(op.u.ln.x, op.u.ln.gamma, op.u.ln.beta, op.u.ln.y, op.u.ln.rows, op.u.ln.C, op.u.ln.eps, op.u.ln.dtype, stream);
+    case SR_OP_ROW_STATS:
+      return sr_row_stats(op.u.ln.x, (float*)op.u.ln.y, op.u.ln.rows, op.u.ln.C, op.u.ln.eps, op.u.ln.dtype, stream);
     case SR_OP_NCHW_TO_NHWC:
       return sr_nchw_to_nhwc((const float*)op.u.cvt.x, op.u.cvt.y, op.u.cvt.B, op.u.cvt.C, op.u.cvt.HW, op.u.cvt.Cpad, op.u.cvt.scale,
                              op.u.cvt.per_batch_scale, op.u.cvt.dtype, stream);

@@ -71,7 +71,7 @@ def workspace(device, nbytes=64 << 20):
 
 
 def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C2=0, bias=None, rowvec=None,
-               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0, tile=0, split=0):
+               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0, tile=0, split=0, row_stats=None, colsum=None):
     ar = L.IgemmArgs()
     ar.a, ar.a2, ar.w, ar.bias, ar.rowvec, ar.residual, ar.out = _p(a), _p(a2), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
     ar.zero_page = _p(zero_page(a.device))
@@ -81,6 +81,7 @@ def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C
     ar.scale = scale
     ar.rowvec_ld = rowvec_ld
     ar.tile, ar.split = tile, split
+    ar.row_stats, ar.colsum = _p(row_stats), _p(colsum)
     ws = workspace(a.device)
     ar.workspace, ar.workspace_bytes = _p(ws), ws.numel()
     return ar
@@ -115,7 +116,7 @@ def tune_igemm(ar, min_flops=1.0e9, reps=4, allow_split=True):
     if flops < min_flops:
         return
     sig = (ar.dtype, ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample, ar.act, ar.transpose_out, ar.out_f32,
-           bool(ar.residual), bool(ar.rowvec), bool(allow_split))
+           bool(ar.residual), bool(ar.rowvec), bool(allow_split), bool(ar.row_stats))
     if sig not in _TUNED:
         lib, st = L.lib(), stream_ptr()
         times = {}
@@ -167,6 +168,26 @@ def groupnorm(x, gamma, beta, B, HW, C1, x2=None, C2=0, groups=32, eps=1e-5, sil
     ar = groupnorm_args(x, gamma, beta, y, B, HW, C1, partials, x2, C2, groups, eps, silu)
     L.check(L.lib().sr_groupnorm(C.byref(ar), stream_ptr()))
     return y
+
+
+def row_stats(x, eps=1e-5):
+    """(rows, C) -> (rows, 2) fp32 (rstd, -rstd*mean): LayerNorm statistics for the folded GEMM form"""
+    rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+    st = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().sr_row_stats(_p(x), _p(st), rows, Cc, eps, DT[x.dtype], stream_ptr()))
+    return st
+
+
+def fold_layernorm(w, bias, gamma, beta, dtype, geglu=False):
+    """Linear(LayerNorm(x)) = rstd*(x . W'^T) - rstd*mean*colsum + bias' with W' = W*gamma, colsum = sum_k W' (of the values the
+    MFMA actually multiplies: rounded to `dtype`), bias' = bias + W . beta.  -> packed W', colsum (N,), bias' (N,) fp32"""
+    w32 = w.float() * gamma.float()[None, :]
+    wq = w32.to(dtype).float()
+    colsum = wq.sum(1)
+    b2 = w.float() @ beta.float()
+    if bias is not None:
+        b2 = b2 + bias.float()
+    return pack_conv_weight(w32, dtype, geglu=geglu), pack_bias(colsum, geglu=geglu), pack_bias(b2, geglu=geglu)
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

@@ -108,7 +108,7 @@ class PlanBuilder:
 
     # ---- ops ------------------------------------------------------------------------------------------
     def igemm(self, a, w, out, B, H, W, C1, N, **kw):
-        self.hold(a, w, out, kw.get("a2"), kw.get("bias"), kw.get("rowvec"), kw.get("residual"))
+        self.hold(a, w, out, kw.get("a2"), kw.get("bias"), kw.get("rowvec"), kw.get("residual"), kw.get("row_stats"), kw.get("colsum"))
         if (kw.get("KH", 1) == 1 and kw.get("stride", 1) == 1 and not kw.get("upsample", 0) and kw.get("rowvec") is None
                 and not kw.get("transpose_out", 0)):
             B, H, W = B * H * W, 1, 1          # a 1x1 convolution IS the linear layer over all pixels: no per-row (b, y, x) split
@@ -137,6 +137,13 @@ class PlanBuilder:
         a.x, a.gamma, a.beta, a.y = O._p(x), O._p(gamma), O._p(beta), O._p(y)
         a.rows, a.C, a.dtype, a.eps = rows, Cc, O.DT[self.dtype], eps
         self._emit(L.OP_LAYERNORM, "ln", a)
+
+    def row_stats(self, x, stats, rows, Cc, eps=1e-5):
+        self.hold(x, stats)
+        a = L._Ln()
+        a.x, a.gamma, a.beta, a.y = O._p(x), None, None, O._p(stats)
+        a.rows, a.C, a.dtype, a.eps = rows, Cc, O.DT[x.dtype], eps
+        self._emit(L.OP_ROW_STATS, "ln", a)
 
     def attention(self, q, k, vt, o, B, Bk, Tq, Tk, heads, d, ldt):
         self.hold(q, k, vt, o)
