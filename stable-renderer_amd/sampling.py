@@ -227,12 +227,12 @@ class DiffusionRunner:
             for si, seg in enumerate(p["segments"]):
                 seg.run()
                 if si < len(p["points"]):
-                    ln, src = p["points"][si]
-                    for j, g in enumerate(self._inject_global):
-                        owner, li = self.shard.owner_of(g)
-                        if owner == self.shard.rank:
-                            src[j].copy_(ln[li])
-                        PAR.broadcast(src[j], owner, self.shard.group)
+                    for ln, src in p["points"][si]:          # the rows and, with the folded LayerNorm, their statistics
+                        for j, g in enumerate(self._inject_global):
+                            owner, li = self.shard.owner_of(g)
+                            if owner == self.shard.rank:
+                                src[j].copy_(ln[li])
+                            PAR.broadcast(src[j], owner, self.shard.group)
             return p["out"]
         if p.get("cn") is not None:                         # ControlNet encoders on the same (x, t, ctx), then their merge
             for cp in p["cn"]["plans"]:

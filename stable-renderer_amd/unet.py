@@ -13,6 +13,8 @@ channel concat without materialising it; time-embedding add, bias, residual and 
 written transposed by its projection so attention needs no transpose; cross-attention K/V depend only on the prompt and
 are projected once per sampling run (prologue plan), not once per step.
 """
+import os
+
 import torch
 
 from . import ops as O
@@ -53,6 +55,19 @@ def pack_weights(sd, dtype, device, pad_cin=(), pad_cout=()):
             w[base + ".g"] = v.float().contiguous().to(device)
             w[base + ".beta"] = b.float().contiguous().to(device)
     shapes = {k[:-7]: tuple(v.shape) for k, v in sd.items() if k.endswith(".weight")}
+    # LayerNorm folded into its consumers (sr_igemm_args.row_stats): norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q,
+    # norm3 -> ff.net.0.proj.  W' = W*gamma, colsum(W'), bias' = bias + W.beta are made once here; the step plan then reads the
+    # un-normalised residual stream and never materialises LN(x) (attention.py:521-654)
+    for k in list(sd):
+        if not k.endswith(".norm1.weight"):
+            continue
+        tb = k[:-len(".norm1.weight")]
+        for norm, lins in (("norm1", ("attn1.to_q", "attn1.to_k", "attn1.to_v")), ("norm2", ("attn2.to_q",)), ("norm3", ("ff.net.0.proj",))):
+            g, bt = sd[f"{tb}.{norm}.weight"], sd[f"{tb}.{norm}.bias"]
+            for lin in lins:
+                base = f"{tb}.{lin}"
+                wf, cs, b2 = O.fold_layernorm(sd[base + ".weight"], sd.get(base + ".bias"), g, bt, dtype, geglu=lin.endswith("ff.net.0.proj"))
+                w[base + ".f"], w[base + ".f.cs"], w[base + ".f.b"] = wf.to(device), cs.to(device), b2.to(device)
     # every ResBlock's emb_layers.1 Linear reads the same SiLU(time embedding): one batched projection per step instead
     # of 22 GEMV-sized launches that each wait on a cold 3 MB weight read (openaimodel.py:262-267)
     embs = [k[:-7] for k in sd if k.endswith(".emb_layers.1.weight")]
@@ -80,6 +95,11 @@ class BlockLowering:
         # after each norm1; ``segments`` are the plans between cuts and ``points`` the (ln, src) buffer pairs the host
         # fills (owner: src <- ln[local index]) and broadcasts before launching the next segment.
         self.external, self.segments, self.points = external, [], []
+        # LayerNorm folded into its consumer GEMMs (pack_weights' ".f" tensors, sr_igemm_args.row_stats): parity-clean, but
+        # measured neutral on the SD1.5 step (22.33 vs 22.27 ms: 0.81 ms of LayerNorm kernels become 0.25 ms of row statistics,
+        # 0.1 ms of extra gathers and +0.3 ms of GEMM epilogue), so the explicit kernels stay the default; SR_FOLD_LN=1 enables
+        # it (not in the view-sharded mode)
+        self.fold_ln = os.environ.get("SR_FOLD_LN", "0") == "1" and not external
         self.emb_all = None
         if "_emb_all" in W:
             ntot, kin = shapes["_emb_all"]
@@ -125,16 +145,38 @@ class BlockLowering:
         mc, heads, emb_s, ctx, n_ctx, ldt_ctx = cfg["model_channels"], cfg["num_heads"], self.emb_s, self.ctx, self.n_ctx, self.ldt_ctx
         inject_idx, sel = self.inject_idx, self.sel
         d = Cc // heads
-        ln = pb.buf(B, HW, Cc)
-        pb.layernorm(hcur, W[p + ".norm1.g"], W[p + ".norm1.beta"], ln, B * HW, Cc)
+        fold = self.fold_ln and (inject_idx is None or (HW * 8) % 16 == 0)     # (the statistics rows are gathered in 16-byte units)
+
+        def normed(x, norm):
+            """-> (tensor the consumers read, folded-LN kwargs factory).  fold: the raw rows + their (rstd, -rstd*mean)"""
+            if not fold:
+                y = pb.buf(B, HW, Cc)
+                pb.layernorm(x, W[f"{p}.{norm}.g"], W[f"{p}.{norm}.beta"], y, B * HW, Cc)
+                return y, None
+            st = pb.buf(B, HW, 2, dtype=torch.float32)
+            pb.row_stats(x, st, B * HW, Cc)
+            return x, st
+
+        def lin(name, st):
+            """weight + epilogue kwargs of a Linear fed by a (possibly folded) LayerNorm"""
+            if st is None:
+                kw = {}
+                if (f"{p}.{name}.b") in W:
+                    kw["bias"] = W[f"{p}.{name}.b"]
+                return W[f"{p}.{name}"], kw
+            return W[f"{p}.{name}.f"], dict(bias=W[f"{p}.{name}.f.b"], row_stats=st, colsum=W[f"{p}.{name}.f.cs"])
+        ln, st1 = normed(hcur, "norm1")
         q = pb.buf(B, HW, Cc)
         if inject_idx is None:
-            pb.igemm(ln, W[p + ".attn1.to_q"], q, B * HW, 1, 1, Cc, Cc)
+            wq, kq = lin("attn1.to_q", st1)
+            pb.igemm(ln, wq, q, B * HW, 1, 1, Cc, Cc, **kq)
             Bk, Tk, ldt = B, HW, _cdiv(HW, 8) * 8     # V^T rows padded to 16 B (pad columns stay zero)
             k = pb.buf(B, HW, Cc)
             vt = pb.buf(B, Cc, ldt, zero=True)
-            pb.igemm(ln, W[p + ".attn1.to_k"], k, B * HW, 1, 1, Cc, Cc)
-            pb.igemm(ln, W[p + ".attn1.to_v"], vt, B, HW, 1, Cc, Cc, transpose_out=1, ldt=ldt)
+            wk, kk = lin("attn1.to_k", st1)
+            wv, kv = lin("attn1.to_v", st1)
+            pb.igemm(ln, wk, k, B * HW, 1, 1, Cc, Cc, **kk)
+            pb.igemm(ln, wv, vt, B, HW, 1, Cc, Cc, transpose_out=1, ldt=ldt, **kv)
         else:
             nr = len(inject_idx)
             Bk, Tk, ldt = 1, nr * HW, _cdiv(nr * HW, 8) * 8
@@ -142,27 +184,33 @@ class BlockLowering:
             vt = pb.buf(1, Cc, ldt, zero=True)
             # K/V of the injected frame(s) only (B-fold fewer projection FLOPs); the frame is picked on the device
             src = pb.buf(nr, HW, Cc)
+            src_st = pb.buf(nr, HW, 2, dtype=torch.float32) if st1 is not None else None
             if self.external:
                 self.segments.append(pb.take())
-                self.points.append((ln, src))
+                self.points.append([(ln, src)] + ([(st1, src_st)] if st1 is not None else []))
             # the injected frame's K / V^T are one-frame GEMMs (latency bound): side lane, beside the B-frame Q projection
             pb.fork()
             with pb.side():
                 if not self.external:
                     pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size())
-                pb.igemm(src, W[p + ".attn1.to_k"], k, Tk, 1, 1, Cc, Cc)
-                pb.igemm(src, W[p + ".attn1.to_v"], vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt)
-            pb.igemm(ln, W[p + ".attn1.to_q"], q, B * HW, 1, 1, Cc, Cc)
+                    if st1 is not None:
+                        pb.gather_rows(st1, sel, src_st, nr, HW * 2 * 4)
+                wk, kk = lin("attn1.to_k", src_st)
+                wv, kv = lin("attn1.to_v", src_st)
+                pb.igemm(src, wk, k, Tk, 1, 1, Cc, Cc, **kk)
+                pb.igemm(src, wv, vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt, **kv)
+            wq, kq = lin("attn1.to_q", st1)
+            pb.igemm(ln, wq, q, B * HW, 1, 1, Cc, Cc, **kq)
             pb.join()
         a = pb.buf(B, HW, Cc)
         pb.attention(q, k, vt, a, B, Bk, HW, Tk, heads, d, ldt)
         h1 = pb.buf(B, HW, Cc)
         pb.igemm(a, W[p + ".attn1.to_out.0"], h1, B * HW, 1, 1, Cc, Cc, bias=W[p + ".attn1.to_out.0.b"], residual=hcur)
         # cross attention: K/V from the prompt, projected once in the prologue plan
-        ln2 = pb.buf(B, HW, Cc)
-        pb.layernorm(h1, W[p + ".norm2.g"], W[p + ".norm2.beta"], ln2, B * HW, Cc)
+        ln2, st2 = normed(h1, "norm2")
         q2 = pb.buf(B, HW, Cc)
-        pb.igemm(ln2, W[p + ".attn2.to_q"], q2, B * HW, 1, 1, Cc, Cc)
+        wq2, kq2 = lin("attn2.to_q", st2)
+        pb.igemm(ln2, wq2, q2, B * HW, 1, 1, Cc, Cc, **kq2)
         k2 = pro.buf(B, n_ctx, Cc)
         vt2 = pro.buf(B, Cc, ldt_ctx, zero=True)
         cd = cfg["context_dim"]
@@ -172,11 +220,11 @@ class BlockLowering:
         pb.attention(q2, k2, vt2, a2, B, B, HW, n_ctx, heads, d, ldt_ctx)
         h2 = pb.buf(B, HW, Cc)
         pb.igemm(a2, W[p + ".attn2.to_out.0"], h2, B * HW, 1, 1, Cc, Cc, bias=W[p + ".attn2.to_out.0.b"], residual=h1)
-        ln3 = pb.buf(B, HW, Cc)
-        pb.layernorm(h2, W[p + ".norm3.g"], W[p + ".norm3.beta"], ln3, B * HW, Cc)
+        ln3, st3 = normed(h2, "norm3")
         inner = self.shapes[p + ".ff.net.0.proj"][0] // 2
         ff = pb.buf(B, HW, inner)
-        pb.igemm(ln3, W[p + ".ff.net.0.proj"], ff, B * HW, 1, 1, Cc, 2 * inner, bias=W[p + ".ff.net.0.proj.b"], act=2)
+        wff, kff = lin("ff.net.0.proj", st3)
+        pb.igemm(ln3, wff, ff, B * HW, 1, 1, Cc, 2 * inner, act=2, **kff)
         h3 = pb.buf(B, HW, Cc)
         pb.igemm(ff, W[p + ".ff.net.2"], h3, B * HW, 1, 1, inner, Cc, bias=W[p + ".ff.net.2.b"], residual=h2)
         return h3

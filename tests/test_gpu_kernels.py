@@ -173,6 +173,51 @@ def test_igemm_forced_tiles(ops, tile, act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["plain", "geglu", "transposed", "residual_big"])
+def test_igemm_folded_layernorm(ops, dtype, mode):
+    """Linear(LayerNorm(x)) with the normalisation folded into the GEMM (sr_row_stats + sr_igemm_args.row_stats/colsum):
+    the GEMM reads the raw rows; rows with a large mean relative to their spread exercise the cancellation"""
+    dev = "cuda"
+    ke = ops.kelems(dtype)
+    M, K, N = (4096 + 13, 320, 640) if mode == "residual_big" else (333, 5 * ke, 256)
+    x = rnd(1, M, K) * 1.7 + rnd(2, M, 1) * 3.0              # per-row offsets up to ~2 sigma
+    gamma, beta = 1 + 0.2 * rnd(3, K), 0.1 * rnd(4, K)
+    w = rnd(5, N, K) * K ** -0.5
+    bias = rnd(6, N) * 0.1
+    xd = x.to(dtype)
+    ln = F.layer_norm(xd.float(), (K,), gamma, beta, 1e-5)
+    ref = ln @ w.to(dtype).float().t() + bias
+    geglu = mode == "geglu"
+    wp, cs, b2 = ops.fold_layernorm(w, bias, gamma, beta, dtype, geglu=geglu)
+    st = ops.row_stats(xd.to(dev))
+    mean, var = xd.float().mean(1), xd.float().var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    assert torch.allclose(st[:, 0].cpu(), rstd, rtol=2e-4) and torch.allclose(st[:, 1].cpu(), -rstd * mean, rtol=2e-4, atol=1e-4)
+    kw = dict(bias=b2.to(dev), row_stats=st, colsum=cs.to(dev))
+    if mode == "transposed":
+        ldt = (M + 7) // 8 * 8
+        out = torch.zeros(1, N, ldt, dtype=dtype, device=dev)
+        ops.igemm(xd.to(dev), wp.to(dev), out, 1, M, 1, K, N, transpose_out=1, ldt=ldt, **kw)
+        got = out[0, :, :M].t()
+    else:
+        nout = N // 2 if geglu else N
+        if geglu:
+            a, g = ref.chunk(2, dim=1)
+            ref = a * F.gelu(g)
+        rs = None
+        if mode == "residual_big":
+            resid = rnd(7, M, N)
+            ref = ref + resid.to(dtype).float()
+            rs = resid.to(dtype).to(dev)
+        out = torch.zeros(M, nout, dtype=dtype, device=dev)
+        ops.igemm(xd.to(dev), wp.to(dev), out, M, 1, 1, K, N, act=2 if geglu else 0, residual=rs, **kw)
+        got = out
+    torch.cuda.synchronize()
+    # the reference rounds LN(x) to `dtype` before the GEMM, the folded form does not: same tolerance class as the GEMM itself
+    close(got, ref, dtype, scale=ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_out_f32_and_scale(ops, dtype):
     ke = ops.kelems(dtype)
     B, T, Cc, N = 2, 50, 2 * ke, 72

@@ -154,3 +154,18 @@ def test_plan_side_lane_fork_join():
         plan.launch()
     torch.cuda.synchronize()
     assert torch.allclose(e, ref, atol=1e-6)
+
+
+def test_unet_tiny_with_folded_layernorm(monkeypatch):
+    """SR_FOLD_LN=1: norm1/2/3 folded into their consumer GEMMs (row statistics + colsum epilogue), incl. the injected-frame
+    gather of raw rows + statistics; same goldens as the explicit-LayerNorm plan"""
+    from stable_renderer_amd.unet import SD15_CFG
+    monkeypatch.setenv("SR_FOLD_LN", "1")
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    d = np.load(os.path.join(GOLD, "unet_tiny.npz"))
+    sd = _sd("unet_tiny_keys.json", 1)
+    for key, inject in (("y", None), ("y_inj", [int(v) for v in np.atleast_1d(d["inj_idx"])])):
+        y, p = run_unet(sd, cfg, torch.float32, T(d["x"]), T(d["t"]), T(d["ctx"]), inject=inject)
+        assert any(p["step"].ops[i].kind == 14 for i in range(p["step"].n)), "row-stats ops expected in the folded plan"
+        ref = T(d[key])
+        assert (y - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
