@@ -574,6 +574,10 @@ static inline int plan_split(int64_t tiles, int KT, int slots, double t_k, int64
   const int64_t full = tiles / slots, tail = tiles - full * slots;
   *tile0 = (int)(full * slots);
   if (tail == 0) return 1;
+  if (const char* fs = getenv("SR_SPLIT_S")) {               // tuning aid: force the split count of the tail round
+    const int S = atoi(fs);
+    if (S >= 1 && KT / S >= 4 && (int64_t)S * tail * tile_ws_bytes <= ws_bytes) return S;
+  }
   double best = (double)KT * t_k;                            // the tail as one more (partly empty) round
   int bestS = 1;
   for (int S = 2; S <= 16; ++S) {

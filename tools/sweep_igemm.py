@@ -31,7 +31,7 @@ shapes = [
     (65536, 1, 1, 320, 2560, 1, 0),
     (16, 8, 8, 1280, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 32, 32, 640, 640, 3, 0), (16, 64, 64, 320, 320, 3, 0),
 ]
-if len(sys.argv) > 1 and sys.argv[1] not in ("splitk", "t5", "t78", "vae"):
+if len(sys.argv) > 1 and sys.argv[1] not in ("splitk", "t5", "t78", "vae", "splits"):
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 if len(sys.argv) > 1 and sys.argv[1] == "t5":
     TILES = (0, 1, 2, 3, 5, 7)
@@ -50,6 +50,23 @@ if len(sys.argv) > 1 and sys.argv[1] == "vae":
     TILES = (0, 1, 2, 8)
     shapes = [(8, 512, 512, 128, 128, 3, 0), (8, 256, 256, 256, 256, 3, 0), (8, 128, 128, 512, 512, 3, 0), (8, 512, 512, 256, 128, 3, 0),
               (16, 64, 64, 1280, 1280, 3, 0), (65536, 1, 1, 320, 2560, 1, 2)]
+if len(sys.argv) > 1 and sys.argv[1] == "splits":
+    os.environ.pop("SR_IGEMM_TILE", None)
+    for sh in [(16, 8, 8, 1280, 1280, 3, 0), (16, 8, 8, 2560, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 16, 16, 2560, 1280, 3, 0),
+               (16, 16, 16, 1920, 1280, 3, 0), (16, 16, 16, 640, 1280, 3, 0)]:
+        row = []
+        for S in (0, 1, 2, 3, 4, 5, 6, 8, 10, 12):
+            if S:
+                os.environ["SR_SPLIT_S"] = str(S)
+            else:
+                os.environ.pop("SR_SPLIT_S", None)
+            best = 1e9
+            for _ in range(2):
+                us, tf = run(*sh)
+                best = min(best, us)
+            row.append(f"S{S}:{best:6.1f}")
+        print("B%d %dx%d C%d N%d k%d act%d | " % sh + " ".join(row), flush=True)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "splitk":
     os.environ.pop("SR_IGEMM_TILE", None)
     for sh in [(16, 8, 8, 1280, 1280, 3, 0), (16, 8, 8, 2560, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 16, 16, 2560, 1280, 3, 0),
