@@ -18,6 +18,7 @@ namespace {
 
 constexpr int TILE = 16;
 constexpr int STAGE = 32;                 // TriRecs staged in LDS at a time
+constexpr int BIN_CH = 8;       // 256-triangle chunks binned per pass (2048 triangles: the sphere proxy in one pass)
 constexpr float PI_F = 3.14159265359f;
 constexpr float CANNY_THRESHOLD = 0.17364817766693041f;   // cos(PI*4/9)
 constexpr int NON_AI_OBJ_MAP_INDEX = 2048;
@@ -142,8 +143,8 @@ __global__ void raster_setup(const sr_draw d, TriRec* __restrict__ recs, int W, 
 
 __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gbuffer g, const TriRec* __restrict__ recs) {
   __shared__ TriRec srec[STAGE];
-  __shared__ int sbin[256];
-  __shared__ int swcnt[4];
+  __shared__ int sbin[BIN_CH * 256];
+  __shared__ int swcnt[BIN_CH * 4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int W = g.W, H = g.H;
   const int tiles_x = (W + TILE - 1) / TILE;
@@ -157,28 +158,59 @@ __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gb
   // per-pixel state
   float zcur = 1.0f;
   if (inimg && d.depth_test) zcur = g.zbuf[pi];
-  bool have_cur = false, touched = false;
+  bool touched = false;
   float curColor[4], curND[4], curNoise[4], curPos[3], curCanny[3];
   int curID[4];
   float oColor[4], oND[4], oNoise[4], oPos[3], oCanny[3];
   int oID[4];
 
-  for (int c0 = 0; c0 < d.nt; c0 += 256) {
-    // ---- bin: which of these 256 triangles touch this tile (order preserving compaction)
-    const int ti = c0 + tid;
-    bool hit = false;
-    if (ti < d.nt) {
-      const int4 bb = *(const int4*)&recs[ti].x0;          // x0,x1,y0,y1
-      const int valid = recs[ti].valid;
-      hit = valid && bb.x <= tx0 + TILE - 1 && bb.y >= tx0 && bb.z <= ty0 + TILE - 1 && bb.w >= ty0;
+  // pre-draw snapshot of this pixel (what the fragment shader blends against): loaded up front so its latency overlaps the
+  // binning pass instead of stalling the first covering triangle
+  if (inimg) {
+    const ushort4 c = ((const ushort4*)g.color)[pi], nd = ((const ushort4*)g.normal_depth)[pi], nz = ((const ushort4*)g.noise)[pi];
+    curColor[0] = h2f(c.x); curColor[1] = h2f(c.y); curColor[2] = h2f(c.z); curColor[3] = h2f(c.w);
+    curND[0] = h2f(nd.x); curND[1] = h2f(nd.y); curND[2] = h2f(nd.z); curND[3] = h2f(nd.w);
+    curNoise[0] = h2f(nz.x); curNoise[1] = h2f(nz.y); curNoise[2] = h2f(nz.z); curNoise[3] = h2f(nz.w);
+    const int4 iv = ((const int4*)g.id)[pi];
+    curID[0] = iv.x; curID[1] = iv.y; curID[2] = iv.z; curID[3] = iv.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { curPos[k] = g.pos[pi * 3 + k]; curCanny[k] = g.canny[pi * 3 + k]; }
+  }
+  // ---- bin: which triangles touch this tile.  Up to BIN_CH x 256 triangles per pass: ALL their bounding-box loads are issued
+  // before the first is used (one memory latency per pass instead of one per 256 triangles), then an order-preserving
+  // compaction over the whole pass (primitive order is the blend order of the TRANSPARENT queue) with two barriers in all.
+  for (int c0 = 0; c0 < d.nt; c0 += BIN_CH * 256) {
+    bool hit[BIN_CH];
+    int4 bb[BIN_CH];
+    int valid[BIN_CH];
+#pragma unroll
+    for (int c = 0; c < BIN_CH; ++c) {
+      const int ti = c0 + c * 256 + tid;
+      bb[c] = make_int4(1, 0, 1, 0);
+      valid[c] = 0;
+      if (ti < d.nt) {
+        bb[c] = *(const int4*)&recs[ti].x0;                 // x0,x1,y0,y1
+        valid[c] = recs[ti].valid;
+      }
     }
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) swcnt[wv] = __popcll(m);
+    unsigned long long m[BIN_CH];
+#pragma unroll
+    for (int c = 0; c < BIN_CH; ++c) {
+      hit[c] = valid[c] && bb[c].x <= tx0 + TILE - 1 && bb[c].y >= tx0 && bb[c].z <= ty0 + TILE - 1 && bb[c].w >= ty0;
+      m[c] = __ballot(hit[c]);
+      if (lane == 0) swcnt[c * 4 + wv] = __popcll(m[c]);
+    }
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wv; ++w) base += swcnt[w];
-    const int total = swcnt[0] + swcnt[1] + swcnt[2] + swcnt[3];
-    if (hit) sbin[base + __popcll(m & ((1ull << lane) - 1ull))] = ti;
+    int total = 0, run = 0;
+#pragma unroll
+    for (int c = 0; c < BIN_CH; ++c)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int n = swcnt[c * 4 + w];
+        if (hit[c] && w == wv) sbin[run + __popcll(m[c] & ((1ull << lane) - 1ull))] = c0 + c * 256 + tid;
+        run += n;
+      }
+    total = run;
     __syncthreads();
     // ---- process binned triangles in order, STAGE records at a time through LDS
     for (int s0 = 0; s0 < total; s0 += STAGE) {
@@ -213,17 +245,6 @@ __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gb
 #pragma unroll
           for (int k = 0; k < 2; ++k) uv[k] = INTERP(T.uv[k], T.uv[2 + k], T.uv[4 + k]);
 #undef INTERP
-          if (!have_cur) {                                   // lazy read of the pre-draw snapshot of this pixel
-            const ushort4 c = ((const ushort4*)g.color)[pi], nd = ((const ushort4*)g.normal_depth)[pi], nz = ((const ushort4*)g.noise)[pi];
-            curColor[0] = h2f(c.x); curColor[1] = h2f(c.y); curColor[2] = h2f(c.z); curColor[3] = h2f(c.w);
-            curND[0] = h2f(nd.x); curND[1] = h2f(nd.y); curND[2] = h2f(nd.z); curND[3] = h2f(nd.w);
-            curNoise[0] = h2f(nz.x); curNoise[1] = h2f(nz.y); curNoise[2] = h2f(nz.z); curNoise[3] = h2f(nz.w);
-            const int4 iv = ((const int4*)g.id)[pi];
-            curID[0] = iv.x; curID[1] = iv.y; curID[2] = iv.z; curID[3] = iv.w;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { curPos[k] = g.pos[pi * 3 + k]; curCanny[k] = g.canny[pi * 3 + k]; }
-            have_cur = true;
-          }
           // ---------------- fragment shader ----------------
           float outNoise[4] = {0.f, 0.f, 0.f, 0.f};
           if (d.noise_tex) {
