@@ -653,9 +653,82 @@ def sec_gbufdump():
          frame=np.int64(frame), **back)
 
 
+def sec_workflow():
+    """(1) the reference's own Workflow.Load + build_prompt (engine/static/workflow.py) on every shipped example graph: the
+    prompt dict, the output-node ids, or the exception type the reference raises for that file; (2) comfy's LoRA key map
+    (comfy/utils.py unet_to_diffusers + comfy/lora.py model_lora_keys_unet's spelling) and merge arithmetic
+    (comfy/lora.py load_lora + model_patcher.calculate_weight) on synthetic LoRA tensors."""
+    import glob
+    import tempfile
+    import types
+    cm = R.import_corrmap()
+    pkg = sys.modules["engine.static"]
+    for n in dir(cm):
+        if not n.startswith("_") and not hasattr(pkg, n):
+            setattr(pkg, n, getattr(cm, n))
+    import folder_paths
+    folder_paths.folder_names_and_paths["custom_nodes"] = ([tempfile.mkdtemp()], set())      # git-ignored dir of the reference
+    with quiet():
+        import engine.static.workflow as W
+    out = {}
+    for path in sorted(glob.glob(os.path.join(R.REF, "resources", "example-workflows", "*.json"))):
+        name = os.path.basename(path)[:-5]
+        try:
+            with quiet():
+                wf = W.Workflow.Load(path)
+                prompt, ids, extra = wf.build_prompt()
+            out[name] = dict(prompt={k: {"inputs": {a: (list(b) if isinstance(b, list) else b) for a, b in v["inputs"].items()},
+                                         "class_type": v["class_type"]} for k, v in prompt.items()},
+                             node_ids_to_be_ran=list(ids), has_output_node=bool(wf.has_output_node))
+        except Exception as e:                                    # noqa: BLE001 - the reference's own failure is the datum
+            out[name] = dict(error=type(e).__name__, message=str(e))
+        print("  workflow", name, "->", "ok" if "prompt" in out[name] else out[name])
+    _jdump(out, os.path.join(GOLD, "workflow_prompts.json"))
+
+    # ---- LoRA
+    import comfy.utils
+    import comfy.lora
+    import comfy.model_patcher
+    from stable_renderer_amd.unet import SD15_CFG
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    cfg = dict(SD15_CFG)
+    ucfg = dict(num_res_blocks=list(cfg["num_res_blocks"]), channel_mult=list(cfg["channel_mult"]),
+                transformer_depth=list(cfg["transformer_depth"]), transformer_depth_output=list(cfg["transformer_depth_output"]),
+                transformer_depth_middle=cfg["transformer_depth_middle"])
+    dk = comfy.utils.unet_to_diffusers(ucfg)
+    names, _ = unet_names_shapes(cfg)
+    have = {n for n, _ in names}
+    km = {}
+    for n, _ in names:                                            # model_lora_keys_unet, without the "diffusion_model." prefix
+        if n.endswith(".weight"):
+            km["lora_unet_" + n[:-7].replace(".", "_")] = n
+    for k, v in dk.items():
+        if k.endswith(".weight") and v in have:
+            km["lora_unet_" + k[:-7].replace(".", "_")] = v
+    _jdump(km, os.path.join(GOLD, "lora_key_map_sd15.json"))
+    g = torch.Generator().manual_seed(31)
+    cases = {"linear": (64, 48), "conv3": (32, 16, 3, 3), "conv1": (24, 40, 1, 1)}
+    arrs = {}
+    mp = types.SimpleNamespace()
+    for name, shp in cases.items():
+        r = 4
+        w = torch.randn(shp, generator=g)
+        up = torch.randn((shp[0], r) + ((1, 1) if len(shp) == 4 else ()), generator=g)
+        down = torch.randn((r, shp[1]) + (tuple(shp[2:]) if len(shp) == 4 else ()), generator=g)
+        for tag, alpha, strength in (("a", None, 1.0), ("b", 2.0, 0.75)):
+            lora = {"m.lora_up.weight": up, "m.lora_down.weight": down}
+            if alpha is not None:
+                lora["m.alpha"] = torch.tensor(alpha)
+            patch = comfy.lora.load_lora(lora, {"m": "w"})["w"]
+            out_w = comfy.model_patcher.ModelPatcher.calculate_weight(mp, [(strength, patch, 1.0)], w.clone(), "w")
+            arrs[f"{name}_{tag}_out"] = out_w.numpy()
+        arrs[f"{name}_w"], arrs[f"{name}_up"], arrs[f"{name}_down"] = w.numpy(), up.numpy(), down.numpy()
+    save("lora_merge", **arrs)
+
+
 SECTIONS = dict(math=sec_math, idmap=sec_idmap, overlap=sec_overlap, corrmap=sec_corrmap, noisepool=sec_noisepool,
                 sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet, legacy=sec_legacy,
-                gbufdump=sec_gbufdump)
+                gbufdump=sec_gbufdump, workflow=sec_workflow)
 
 if __name__ == "__main__":
     todo = _ARGV or list(SECTIONS)

@@ -2,6 +2,7 @@
 ``__call__`` signatures (comfyUI/stable_rendering/_nodes/{data,samplers}.py, comfyUI/nodes.py VAEDecode/custom_ksampler),
 executing on the HIP path.  The node *registration* machinery (AdvancedNodeBase -> ComfyUI web UI, node_base.py:179-686) is
 UI plumbing and out of scope; a graph executor only needs these callables."""
+import copy
 import os
 from functools import partial
 from typing import Callable, Optional, Tuple
@@ -22,23 +23,50 @@ class StableRenderingNode:
 
 
 class MODEL:
-    """What CheckpointLoaderSimple hands to samplers here: a HIP UNet (+ lazily built runners keyed by batch/shape)."""
+    """What CheckpointLoaderSimple hands to samplers here: a HIP UNet (+ lazily built runners keyed by batch/shape/ControlNets).
+    ``state_dict`` (host tensors) is kept when a later LoraLoaderModelOnly must re-pack patched weights."""
 
-    def __init__(self, unet):
-        self.unet = unet
+    def __init__(self, unet, state_dict=None, cfg=None, dtype=None):
+        self.unet, self.state_dict = unet, state_dict
+        self.cfg = cfg if cfg is not None else unet.cfg
+        self.dtype = dtype if dtype is not None else unet.dtype
         self._runners = {}
 
-    def runner(self, N, h, w, cfg, use_graph=True):
-        key = (N, h, w, float(cfg), use_graph)
+    def runner(self, N, h, w, cfg, use_graph=True, controlnets=()):
+        key = (N, h, w, float(cfg), use_graph, tuple((id(c), c.strength) for c in controlnets))
         if key not in self._runners:
-            self._runners[key] = DiffusionRunner(self.unet, N, h, w, cfg, use_graph=use_graph)
+            self._runners[key] = DiffusionRunner(self.unet, N, h, w, cfg, use_graph=use_graph, controlnets=list(controlnets))
         return self._runners[key]
+
+
+def unwrap_conditioning(c):
+    """CONDITIONING ([[cond, {..., 'control': AppliedControl}], ...], comfyUI/nodes.py:53-65, 806-848) or a bare
+    (1|N, 77, ctx) tensor -> (tensor, [AppliedControl, ...] newest first)"""
+    if isinstance(c, torch.Tensor):
+        return c, []
+    if len(c) != 1:
+        raise NotImplementedError(f"{len(c)} conditionings in one list (area / mask composition, comfy/samplers.py:90-206) "
+                                  "is not on the hot path; the shipped workflows produce one (SceneTextEncode merge=True)")
+    cond, extra = c[0]
+    if extra.get("mask") is not None or extra.get("area") is not None:
+        raise NotImplementedError("masked / area conditioning")
+    if float(extra.get("strength", 1.0)) != 1.0:
+        raise NotImplementedError("conditioning strength != 1 only acts through area composition")
+    ctl = extra.get("control")
+    return cond, (ctl.chain() if ctl is not None else [])
 
 
 class EngineDataNode(StableRenderingNode):
     """_nodes/data.py:36-63: unpack the hidden EngineData into its 11 outputs."""
 
+    N_OUTPUTS = 11
+
+    def IsChanged(self, engine_data: EngineData):
+        return None if engine_data is None else engine_data.serial      # a new EngineData per engine frame (data.py:65-69)
+
     def __call__(self, engine_data: EngineData):
+        if engine_data is None:
+            return (None, None, None, None, None, None, None, None, None, {}, "")
         return (engine_data.color_maps, engine_data.id_maps, engine_data.pos_maps, engine_data.normal_maps,
                 engine_data.depth_maps, engine_data.canny_maps, engine_data.noise_maps, engine_data.masks,
                 engine_data.correspond_maps, engine_data.sprite_infos, engine_data.env_prompts)
@@ -49,7 +77,16 @@ class VirtualEngineDataNode(StableRenderingNode):
     PriorNode = True
 
     def __call__(self, color_maps=None, id_maps=None, pos_maps=None, normal_maps=None, depth_maps=None, canny_maps=None,
-                 noise_maps=None, masks=None, correspond_maps=None, sprites=None, env_prompt=None) -> EngineData:
+                 noise_maps=None, masks=None, correspond_maps=None, sprites=None, env_prompt=None, context=None) -> EngineData:
+        ed = self._make(color_maps, id_maps, pos_maps, normal_maps, depth_maps, canny_maps, noise_maps, masks, correspond_maps,
+                        sprites, env_prompt)
+        if context is not None:
+            context.engine_data = ed          # later nodes' hidden EngineData input (data.py:88-105)
+        return ed
+
+    @staticmethod
+    def _make(color_maps, id_maps, pos_maps, normal_maps, depth_maps, canny_maps, noise_maps, masks, correspond_maps, sprites,
+              env_prompt):
         n = len(id_maps) if id_maps is not None else (0 if color_maps is None else len(color_maps))
         return EngineData(frame_indices=list(range(n)), color_maps=color_maps, id_maps=id_maps, pos_maps=pos_maps,
                           normal_maps=normal_maps, depth_maps=depth_maps, canny_maps=canny_maps, noise_maps=noise_maps,
@@ -158,6 +195,12 @@ class InferenceOutputNode(StableRenderingNode):
     IsOutputNode = True
     Unique = True
 
+    @classmethod
+    def INPUT_TYPES(cls):
+        # `save` belongs to __server_call__ (data.py:126-139); graphs saved from the web UI carry it
+        return {"required": {"colorImg": ("IMAGE", {})}, "optional": {"save": ("BOOLEAN", {"default": False})},
+                "hidden": {"context": "INFERENCE_CONTEXT"}}
+
     def __call__(self, colorImg, context=None) -> InferenceOutput:
         out = InferenceOutput(colorImg)
         if context is not None:
@@ -168,6 +211,7 @@ class InferenceOutputNode(StableRenderingNode):
 class DefaultCorresponder(StableRenderingNode):
     """_nodes/samplers.py:20-68 -> (Corresponder, VAEDecodeCallback)"""
     Category = "sampling"
+    N_OUTPUTS = 2
 
     def __call__(self, engine_data: EngineData, update_corrmap: bool = True, update_mode='first_avg',
                  post_attn_inject_ratio: float = 0.6) -> Tuple[object, Callable]:
@@ -179,6 +223,7 @@ class DefaultCorresponder(StableRenderingNode):
 class OverlapCorresponder(StableRenderingNode):
     """_nodes/samplers.py:71-125; the reference's OverlapCorresponder has no ``finished`` -> do-nothing VAE callback"""
     Category = "sampling"
+    N_OUTPUTS = 2
 
     def __call__(self, engine_data: EngineData, update_corrmap: bool = True, update_mode='first_avg',
                  pre_attn_inject_num_of_random_frames: int = 1, post_attn_inject_ratio: float = 0.6,
@@ -195,9 +240,12 @@ class OverlapCorresponder(StableRenderingNode):
 
 def custom_ksampler(model: MODEL, seed, steps, cfg, sampler_name, scheduler, positive, negative, latent, denoise=1.0,
                     noise_option='random', callbacks=None, engine_data=None, corresponder=None, **kwargs):
-    """comfyUI/nodes.py:1438-1495.  positive / negative: (1|N, 77, ctx) embeddings (conditioning lists are unwrapped by the
-    caller).  ``engine_data`` / ``corresponder`` reach the attention blocks through the plan (K/V injection)."""
+    """comfyUI/nodes.py:1438-1495.  positive / negative: CONDITIONING lists or bare (1|N, 77, ctx) embeddings; ControlNets
+    applied to the positive conditioning serve both halves of the batch (control_apply_to_uncond, samplers.py:520-548).
+    ``engine_data`` / ``corresponder`` reach the attention blocks through the plan (K/V injection)."""
     latent_image = latent["samples"]
+    positive, controls = unwrap_conditioning(positive)
+    negative, _ = unwrap_conditioning(negative)
     N, _, h, w = latent_image.shape
     if noise_option == 'disable':
         noise = torch.zeros_like(latent_image)
@@ -210,8 +258,20 @@ def custom_ksampler(model: MODEL, seed, steps, cfg, sampler_name, scheduler, pos
         noise = torch.randn(latent_image.size(), dtype=latent_image.dtype, generator=g, device="cpu")
     else:
         raise ValueError(f"Invalid noise option: {noise_option}")
-    run = model.runner(N, h, w, cfg)
+    nets = []
+    for c in controls:
+        net = c.net
+        if net.strength != c.strength:                 # same packed weights, its own strength (set_cond_hint(hint, strength))
+            cache = net.__dict__.setdefault("_by_strength", {})
+            if c.strength not in cache:
+                cache[c.strength] = copy.copy(net)
+                cache[c.strength].strength = c.strength
+            net = cache[c.strength]
+        nets.append(net)
+    run = model.runner(N, h, w, cfg, controlnets=nets)
     run.set_conditioning(positive, negative)
+    if controls:
+        run.set_control_hints([c.hint for c in controls])
     n_rand = None
     if corresponder is not None and engine_data is not None and isinstance(corresponder, _OverlapCorresponder):
         n_rand = corresponder.pre_attn_inject_num_random_frames

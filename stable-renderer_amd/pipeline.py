@@ -50,7 +50,7 @@ class BakeBallScene:
 
 class FramePipeline:
     def __init__(self, unet, vae, scene, n_views=8, steps=20, cfg=8.0, sampler="ddim", scheduler="normal",
-                 corresponder=None, use_graph=True, bg_seed=1, shard=None, controls=None):
+                 corresponder=None, use_graph=True, bg_seed=1, shard=None, controls=None, keep_planes=False):
         """shard: optional parallel.ViewShard over the ``n_views`` of ONE overlapped group (one process per GPU): this process
         then rasterises / diffuses / decodes only its own views; id maps are all-gathered once per call, latents once per
         overlap step, the injected frame's tokens are broadcast per transformer block and decoded frames go to rank 0 for
@@ -86,8 +86,10 @@ class FramePipeline:
         self.colors = torch.zeros(n_views, self.H, self.W, 3, dtype=torch.float16, device=dev)
         self.masks = torch.zeros(n_views, self.H, self.W, dtype=torch.float16, device=dev)
         self.noise = torch.zeros(n_views, 4, self.h, self.w, dtype=torch.float32, device=dev)
-        self.normal_depth = torch.zeros(n_views, self.H, self.W, 4, dtype=torch.float16, device=dev) if self.controls else None
-        self.canny = torch.zeros(n_views, self.H, self.W, 3, dtype=torch.float32, device=dev) if self.controls else None
+        # keep_planes: EngineData also carries normal / depth / canny maps (what a workflow graph's ControlNetApply nodes read)
+        self.keep_planes = bool(keep_planes or self.controls)
+        self.normal_depth = torch.zeros(n_views, self.H, self.W, 4, dtype=torch.float16, device=dev) if self.keep_planes else None
+        self.canny = torch.zeros(n_views, self.H, self.W, 3, dtype=torch.float32, device=dev) if self.keep_planes else None
         self.frame0 = 0
 
     def set_prompt(self, positive, negative):
@@ -102,7 +104,7 @@ class FramePipeline:
             self.colors[i].copy_(self.gbuf.color[..., :3])
             alpha = self.gbuf.color[..., 3].contiguous()
             self.masks[i].copy_(1.0 - alpha)
-            if self.controls:
+            if self.keep_planes:
                 self.normal_depth[i].copy_(self.gbuf.normal_depth)
                 self.canny[i].copy_(self.gbuf.canny)
             _, nz = O.noise_pool(self.gbuf.noise.unsqueeze(0), alpha.unsqueeze(0), self.bg_noise)
@@ -112,7 +114,11 @@ class FramePipeline:
         self._ids_all = None
         if self.shard is not None:
             self._ids_all = IDMap(self.shard.gather_latents(self.ids))        # every rank needs every view's ids
-        return EngineData(frame_indices=list(range(self.N)), color_maps=self.colors, id_maps=idm, masks=self.masks,
+        planes = {}
+        if self.keep_planes:                                    # _save_frame_data: normal = rgb, depth = a repeated to 3 channels
+            planes = dict(normal_maps=self.normal_depth[..., :3], depth_maps=self.normal_depth[..., 3:4].expand(-1, -1, -1, 3),
+                          canny_maps=self.canny)
+        return EngineData(frame_indices=list(range(self.N)), color_maps=self.colors, id_maps=idm, masks=self.masks, **planes,
                           noise_maps=LATENT(samples=torch.zeros_like(self.noise), noise=self.noise),
                           correspond_maps={(self.scene.sprite, self.scene.material): self.scene.corrmap})
 

@@ -1,11 +1,37 @@
 """Data types that cross the hot path (comfyUI/types/hidden.py:249-351 EngineData; comfyUI/types/basic.py LATENT).
 Containers only: every tensor is an ordinary torch tensor living in HBM."""
+import itertools
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 
 from .corrmap import CorrespondMap, IDMap
+
+_SERIAL = itertools.count(1)
+
+
+@dataclass
+class Sprite:
+    """common_utils/stable_render_utils/sprite.py:15-32"""
+    spriteID: int
+    prompt: str = ""
+    prompt_weight: float = 1.0
+    neg_prompt: str = ""
+    neg_prompt_weight: float = 1.0
+
+
+class SpriteInfos(dict):
+    """{spriteID: Sprite} (sprite.py:35-39)"""
+
+
+@dataclass
+class EnvPrompt:
+    """common_utils/stable_render_utils/prompts.py:4-19"""
+    prompt: str = ""
+    negative_prompt: str = ""
+    weight: float = 1.0
+    negative_weight: float = 1.0
 
 
 class LATENT(dict):
@@ -26,6 +52,7 @@ class EngineData:
     correspond_maps: Optional[Dict[Tuple[int, int], CorrespondMap]] = None
     sprite_infos: Any = None
     env_prompts: Any = None
+    serial: int = field(default_factory=lambda: next(_SERIAL))     # a fresh value per EngineData: EngineDataNode.IsChanged
 
     @property
     def frame_count(self):

@@ -1,0 +1,127 @@
+"""The shipped workflow graphs (tests/golden/workflows/*.json = resources/example-workflows of the reference) executed by
+workflow.PromptExecutor on the HIP path: graph result == the same nodes called by hand; loaders are cached across frames while
+everything fed by the frame's EngineData re-runs."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+WF = os.path.join(os.path.dirname(__file__), "golden", "workflows")
+H = W_ = 256                                                    # ControlNetApply only moves channels for images >= 256 px
+
+
+def _register(monkeypatch):
+    from stable_renderer_amd import synth, weights as WT
+    from stable_renderer_amd.graph_nodes import SyntheticCLIP
+    from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes, controlnet_names_shapes
+    from stable_renderer_amd.unet import SD15_CFG
+    monkeypatch.setenv("SR_DTYPE", "fp32")
+    monkeypatch.setenv("SR_AUTOTUNE", "0")                     # same tiles in both plan builds -> bit-identical results
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    ns, norms = unet_names_shapes(cfg)
+    vns, vnorms = vae_decoder_names_shapes(ch=32)
+    cns, cnorms = controlnet_names_shapes(cfg)
+    WT.clear_registry()
+    WT.register_checkpoint("dreamshaper_8.safetensors", lambda: dict(
+        unet=synth.synth_state_dict(ns, seed=1, norm_names=norms), vae=synth.synth_state_dict(vns, seed=3, norm_names=vnorms),
+        clip=SyntheticCLIP(ctx_dim=64), unet_cfg=cfg))
+    for i, name in enumerate(("control_v11f1p_sd15_depth_fp16.safetensors", "control_v11p_sd15_normalbae_fp16.safetensors")):
+        WT.register_controlnet(name, lambda i=i: dict(state_dict=synth.synth_state_dict(cns, seed=20 + i, norm_names=cnorms), cfg=cfg))
+    g = torch.Generator().manual_seed(9)
+    lora = {}
+    for mod, (o, i_) in (("lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q", (64, 64)),
+                         ("lora_unet_mid_block_attentions_0_proj_in", (256, 256)),
+                         ("lora_unet_up_blocks_3_resnets_2_conv1", (64, 128))):
+        r = 4
+        lora[mod + ".lora_up.weight"] = 0.05 * torch.randn((o, r) + ((1, 1) if mod.endswith("conv1") else ()), generator=g)
+        lora[mod + ".lora_down.weight"] = 0.05 * torch.randn((r, i_) + ((3, 3) if mod.endswith("conv1") else ()), generator=g)
+        lora[mod + ".alpha"] = torch.tensor(2.0)
+    WT.register_lora("lcm/SD1.5/pytorch_lora_weights.safetensors", lambda: dict(lora))
+    return cfg
+
+
+def _engine_data(seed, N=2, k=3):
+    from stable_renderer_amd.corrmap import CorrespondMap, IDMap
+    from stable_renderer_amd.types import EngineData, EnvPrompt, LATENT, Sprite, SpriteInfos
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(N, H, W_, 4, dtype=torch.int32)
+    ids[..., 0], ids[..., 1] = 1, 1
+    ids[..., 2] = torch.randint(0, k * k, (N, H, W_), generator=g, dtype=torch.int32)
+    ids[..., 3] = torch.randint(0, H * W_, (N, H, W_), generator=g, dtype=torch.int32)          # fully covered frames
+    dev = "cuda"
+    return EngineData(frame_indices=list(range(N)), id_maps=IDMap(ids.to(dev)),
+                      color_maps=torch.rand(N, H, W_, 3, generator=g).to(dev), normal_maps=torch.rand(N, H, W_, 3, generator=g).to(dev),
+                      depth_maps=torch.rand(N, H, W_, 1, generator=g).expand(-1, -1, -1, 3).contiguous().to(dev),
+                      noise_maps=LATENT(samples=torch.zeros(N, 4, H // 8, W_ // 8).to(dev), noise=torch.randn(N, 4, H // 8, W_ // 8, generator=g).to(dev)),
+                      correspond_maps={(1, 1): CorrespondMap(k=k, width=W_, height=H)},
+                      sprite_infos=SpriteInfos({1: Sprite(1, prompt="a red ball", neg_prompt="blurry")}),
+                      env_prompts=[EnvPrompt(prompt="forest", negative_prompt="watermark")])
+
+
+def _by_hand(ed, controls):
+    """bake.json spelled out as direct node calls"""
+    from stable_renderer_amd import graph_nodes as G, nodes as Nn
+    model, clip, vae = G.CheckpointLoaderSimple().load_checkpoint("dreamshaper_8.safetensors")
+    (model,) = G.LoraLoaderModelOnly().load_lora_model_only(model, "lcm\\SD1.5\\pytorch_lora_weights.safetensors", 1)
+    assert model.lora_unused_keys == []
+    pos, neg = G.SceneTextEncode()(clip, ed.sprite_infos, ed.env_prompts, True, ed.id_maps)
+    for name, img in controls:
+        (cn,) = G.ControlNetLoader().load_controlnet(name)
+        (pos,) = G.ControlNetApply().apply_controlnet(pos, cn, img, 1)
+    corr, cb = Nn.DefaultCorresponder()(ed, True, "first_avg", 0.6)
+    lat = Nn.CorrespondSampler()(model, pos, neg, corr, ed, latent=ed.noise_maps, steps=4, cfg=2, sampler_name="euler",
+                                 scheduler="sgm_uniform", denoise=1)
+    (img,) = G.VAEDecode().decode(vae, lat, cb)
+    return img.clone()
+
+
+@pytest.mark.parametrize("graph", ["bake", "no-control-bake"])
+def test_shipped_graph_equals_direct_node_calls(graph, monkeypatch):
+    from stable_renderer_amd import workflow as W
+    _register(monkeypatch)
+    ed = _engine_data(5)
+    ex = W.PromptExecutor(dev_mode=True)
+    ctx = W.run_workflow(os.path.join(WF, graph + ".json"), engine_data=ed, executor=ex)
+    assert ctx.success and ctx.final_output is not None
+    img = ctx.final_output.frame_color.clone()
+    assert tuple(img.shape) == (2, H, W_, 3) and float(img.min()) >= 0 and float(img.max()) <= 1 and float(img.std()) > 0
+    cm = ed.correspond_maps[(1, 1)]
+    written = int(cm._writtens.sum())
+    assert written > 0                                                   # VAEDecode.callback -> DefaultCorresponder.finished
+    vals = cm._values.clone()
+
+    ed2 = _engine_data(5)                                                # same frame again, fresh corr-map, by hand
+    controls = [("control_v11p_sd15_normalbae_fp16.safetensors", ed2.normal_maps),
+                ("control_v11f1p_sd15_depth_fp16.safetensors", ed2.depth_maps)] if graph == "bake" else []
+    ref = _by_hand(ed2, controls)
+    torch.cuda.synchronize()
+    assert torch.equal(img, ref)
+    assert torch.equal(vals, ed2.correspond_maps[(1, 1)]._values) and written == int(ed2.correspond_maps[(1, 1)]._writtens.sum())
+
+
+def test_loaders_are_cached_across_frames(monkeypatch):
+    from stable_renderer_amd import workflow as W
+    _register(monkeypatch)
+    ex = W.PromptExecutor(dev_mode=True)
+    wf = W.Workflow.Load(os.path.join(WF, "bake.json"))
+    first = W.run_workflow(wf, engine_data=_engine_data(5), executor=ex)
+    loaders = {"4", "11", "29", "31"}                                    # checkpoint, LoRA, two ControlNets
+    assert loaders <= first.executed_node_ids
+    img1 = first.final_output.frame_color.clone()
+    second = W.run_workflow(wf, engine_data=_engine_data(6), executor=ex)
+    assert second.success and not (loaders & second.executed_node_ids)
+    assert {"38", "39", "37", "47", "8", "23", "30", "32"} <= second.executed_node_ids      # everything fed by the frame re-ran
+    assert not torch.equal(img1, second.final_output.frame_color)
+    same = W.run_workflow(wf, engine_data=second.engine_data, executor=ex)                   # identical frame: all cached
+    assert same.success and same.executed_node_ids == set()
+
+
+def test_missing_weights_fail_loudly(monkeypatch):
+    from stable_renderer_amd import weights as WT, workflow as W
+    monkeypatch.delenv("SR_MODELS_DIR", raising=False)
+    WT.clear_registry()
+    ctx = W.run_workflow(os.path.join(WF, "no-control-bake.json"), engine_data=_engine_data(5), executor=W.PromptExecutor(dev_mode=False))
+    assert not ctx.success and ctx.final_output is None
+    ev, mes = ctx.status_messages[-1]
+    assert ev == "execution_error" and mes["node_type"] == "CheckpointLoaderSimple" and "FileNotFoundError" in mes["exception_type"]
