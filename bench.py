@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="build the pipeline, run ONE call, then only the igemm-subset replays of the roofline object (the command "
                          "profiled with rocprofv3 for profiles/: its kernel stats then cover exactly those launches)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="bake calls in flight on each GPU (pipeline.InflightCalls: one host thread + HIP stream + launch plans per "
+                         "slot, RNG draws and corr-map updates kept in call order -> same results as 1); 1 = the plain call loop")
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"],
                     help="replica: every GPU bakes its own 8-view group (weak scaling, no collective); shard: ONE 8-view group "
                          "split over the GPUs with the latent all-gather / K,V-source broadcast over RCCL (strong scaling)")
@@ -102,13 +105,23 @@ def main():
     if a.roofline_only:                                       # no calls: just the UNet step plan (as a sampling run builds it)
         a.warmup, a.steps, a.no_cpu_baseline = 0, 0, True
         pipe.runner._load_ctx(pipe.runner._ensure_plan([3]))
-    for _ in range(a.warmup):
-        pipe.call()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        pipe.call()
-    sync()
+    inflight = max(1, a.inflight) if (shard is None and not a.roofline_only) else 1
+    if inflight > 1:
+        from stable_renderer_amd.pipeline import InflightCalls
+        fl = InflightCalls(pipe, inflight)
+        fl.warm(a.warmup)                                     # every slot builds / tunes / captures alone, W calls each
+        sync()
+        t0 = time.perf_counter()
+        fl.run(a.steps)                                       # exactly K calls, call c on slot c % inflight
+        sync()
+    else:
+        for _ in range(a.warmup):
+            pipe.call()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            pipe.call()
+        sync()
     dt = max(time.perf_counter() - t0, 1e-9)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -163,7 +176,8 @@ def main():
                                       "OverlapCorresponder (per-step latent overlap + K/V injection) -> VAE decode %dx512^2 -> corr-map "
                                       "update; zero latent + engine noise as the reference bake workflows; one call per step"
                                       % (a.denoise_steps, a.views, a.views),
-                          "views_per_call": a.views, "denoise_steps": a.denoise_steps, "resolution": 512, "parallelism": ("one group view-sharded x%d" if shard is not None else "view-group replicas x%d") % world},
+                          "views_per_call": a.views, "denoise_steps": a.denoise_steps, "resolution": 512, "parallelism": ("one group view-sharded x%d" if shard is not None else "view-group replicas x%d") % world,
+                          "calls_in_flight_per_gpu": inflight},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist is not None:

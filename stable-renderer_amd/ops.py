@@ -1,7 +1,9 @@
 """Thin torch-tensor wrappers over the C ABI (plumbing only: pointers, shapes, streams).  Every function
 launches HIP kernels from libsr_hip.so; nothing here computes on the CPU or through torch ops."""
+import contextlib
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -60,11 +62,25 @@ def pack_bias(b, geglu=False):
 
 
 _WS = {}
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def workspace_slot(slot):
+    """Plans built (and eager igemms issued) by this thread inside the context use split-K scratch number ``slot``: calls in
+    flight on different streams (pipeline.InflightCalls) must not share it."""
+    prev = getattr(_tls, "slot", 0)
+    _tls.slot = slot
+    try:
+        yield
+    finally:
+        _tls.slot = prev
 
 
 def workspace(device, nbytes=64 << 20):
-    """per-device fp32 scratch shared by every igemm on the stream (split-K partials; dead after each call)"""
-    key = str(device)
+    """per-device (and per in-flight slot) fp32 scratch shared by every igemm on one stream (split-K partials; dead after each
+    call)"""
+    key = (str(device), getattr(_tls, "slot", 0))
     if key not in _WS:
         _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return _WS[key]

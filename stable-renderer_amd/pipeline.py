@@ -9,7 +9,10 @@
 
 This is the body of the reference's bake call (DiffusionManager.SubmitPrompt with a bake workflow,
 diffusionManager.py:289-352) for a scene of the ``scripts/bake_ball.py`` kind; all stages stay in HBM."""
+import contextlib
+import copy
 import math
+import threading
 
 import torch
 
@@ -46,6 +49,95 @@ class BakeBallScene:
             S.DrawTask(self.sphere, m2, sprite_id=self.sprite, material_id=self.material, render_mode=2, corrmap_k=self.k,
                        use_texcoord_id=True, id_size=(self.W, self.H), noise_tex=self.noise_tex, order=2000.3),
         ]
+
+
+class CallOrder:
+    """Tickets for the two sections of a call that touch process-wide state — the draws on the global CPU generator at the
+    start of sampling and the frame-ordered ('first' priority) corr-map update — so that calls in flight on several streams
+    execute them in call order and produce exactly what the sequential loop produces."""
+
+    def __init__(self, first=0):
+        self._cv = threading.Condition()
+        self._next = {"rng": first, "bake": first}
+        self._failed = False
+
+    @contextlib.contextmanager
+    def turn(self, kind, index):
+        with self._cv:
+            self._cv.wait_for(lambda: self._next[kind] == index or self._failed)
+            if self._failed:
+                raise RuntimeError("another in-flight call failed")
+        try:
+            yield
+        except BaseException:
+            with self._cv:
+                self._failed = True
+                self._cv.notify_all()
+            raise
+        with self._cv:
+            self._next[kind] = index + 1
+            self._cv.notify_all()
+
+    def fail(self):
+        with self._cv:
+            self._failed = True
+            self._cv.notify_all()
+
+
+class InflightCalls:
+    """K bake calls in flight on one GPU: one host thread + HIP stream + FramePipeline (own launch plans, hipGraph, G-buffer
+    and split-K scratch; shared weights, scene and corr-map) per slot.  A single call leaves CUs idle in every kernel's tail
+    wave and in the launch gaps of ~600 kernels per UNet evaluation; a second call's kernels fill them.  Sampling never reads
+    the corr-map (BAKING mode rasterises ids, not colours), so only the RNG draws and the corr-map updates are ordered
+    (CallOrder); frames are numbered as the sequential loop numbers them."""
+
+    def __init__(self, pipe, inflight=2):
+        self.pipes = [pipe] + [pipe.spawn(i) for i in range(1, inflight)]
+        self.streams = [torch.cuda.Stream(device=pipe.unet.device) for _ in self.pipes]
+
+    def warm(self, calls=1):
+        """build plans / tune tiles / capture graphs one pipeline at a time (timing-based tuning and graph capture want the GPU
+        to themselves); every pipeline ends on its own stream"""
+        for i, (p, st) in enumerate(zip(self.pipes, self.streams)):
+            with torch.cuda.stream(st), O.workspace_slot(i):
+                for _ in range(calls):
+                    p.call()
+            st.synchronize()
+        self._sync_frames()
+
+    def _sync_frames(self):
+        f = max(p.frame0 for p in self.pipes)
+        for p in self.pipes:
+            p.frame0 = f
+
+    def run(self, n_calls):
+        """n_calls calls, call c handled by slot c % K -> list of per-call outputs is not kept (the corr-map is the product);
+        returns after every stream has drained"""
+        base = self.pipes[0].frame0
+        order = CallOrder()
+        errs = []
+        torch.cuda.synchronize()
+
+        def work(i):
+            p, st = self.pipes[i], self.streams[i]
+            try:
+                with torch.cuda.stream(st), O.workspace_slot(i):
+                    for c in range(i, n_calls, len(self.pipes)):
+                        p.frame0 = base + c * p.N_all
+                        p.call(order=(order, c))
+                    st.synchronize()
+            except BaseException as e:                      # noqa: BLE001 - re-raised on the caller's thread
+                errs.append(e)
+                order.fail()
+        ts = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(self.pipes))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+        for p in self.pipes:
+            p.frame0 = base + n_calls * p.N_all
 
 
 class FramePipeline:
@@ -93,7 +185,23 @@ class FramePipeline:
         self.frame0 = 0
 
     def set_prompt(self, positive, negative):
+        self._prompt = (positive, negative)
         self.runner.set_conditioning(positive, negative)
+
+    def spawn(self, slot):
+        """a second pipeline over the SAME weights, scene and corr-map with its own plans / buffers (InflightCalls); built with
+        split-K scratch number ``slot``"""
+        if self.shard is not None:
+            raise NotImplementedError("calls in flight together with a view-sharded group")
+        with O.workspace_slot(slot):
+            p = FramePipeline(self.unet, self.vae, self.scene, n_views=self.N_all, steps=self.steps, cfg=self.cfg,
+                              sampler=self.sampler, scheduler=self.scheduler, corresponder=copy.copy(self.corresponder),
+                              use_graph=self.runner.use_graph, controls=self.controls, keep_planes=self.keep_planes)
+        p.bg_noise = self.bg_noise
+        p.frame0 = self.frame0
+        if getattr(self, "_prompt", None) is not None:
+            p.set_prompt(*self._prompt)
+        return p
 
     def render_views(self):
         """N consecutive frames -> EngineData (the per-frame part of _save_frame_data)."""
@@ -122,7 +230,7 @@ class FramePipeline:
                           noise_maps=LATENT(samples=torch.zeros_like(self.noise), noise=self.noise),
                           correspond_maps={(self.scene.sprite, self.scene.material): self.scene.corrmap})
 
-    def diffuse(self, ed):
+    def diffuse(self, ed, rng_turn=None):
         corr = self.corresponder
         cb, n_rand = None, None
         if isinstance(corr, OverlapCorresponder):
@@ -145,7 +253,8 @@ class FramePipeline:
                       "color": lambda: self.colors, "canny": lambda: self.canny}
             self.runner.set_control_hints([planes[k]().permute(0, 3, 1, 2).float().contiguous() for k, _ in self.controls])
         samples, inj = self.runner.sample(ed.noise_maps["noise"], self.steps, self.sampler, self.scheduler,
-                                          latent_image=ed.noise_maps["samples"], inject_n_rand=n_rand, step_callback=cb)
+                                          latent_image=ed.noise_maps["samples"], inject_n_rand=n_rand, step_callback=cb,
+                                          rng_turn=rng_turn)
         if isinstance(corr, OverlapCorresponder) and inj is not None:
             corr._random_frame_indices = torch.tensor(inj)
         return samples
@@ -155,9 +264,10 @@ class FramePipeline:
         self.vplan["plan"].run()
         return self.vplan["img"]                       # (N, H, W, 3) fp32 in [0,1]
 
-    def call(self, timings=None):
+    def call(self, timings=None, order=None):
         """one bake call = N frames; returns the decoded frames.  timings: optional dict filled with per-stage wall ms
-        (forces a device sync after every stage: diagnostics only)."""
+        (forces a device sync after every stage: diagnostics only).  order: (CallOrder, call index) when several calls are in
+        flight (InflightCalls)."""
         import time
 
         def mark(name, t0):
@@ -168,12 +278,15 @@ class FramePipeline:
         t = time.perf_counter()
         ed = self.render_views()
         t = mark("raster+engine_data", t)
-        samples = self.diffuse(ed)
+        samples = self.diffuse(ed, rng_turn=None if order is None else order[0].turn("rng", order[1]))
         t = mark("sampling", t)
         images = self.decode(samples)
         t = mark("vae_decode", t)
         if self.shard is None:
-            self.baker.finished(ed, images)
+            with (contextlib.nullcontext() if order is None else order[0].turn("bake", order[1])):
+                self.baker.finished(ed, images)
+                if order is not None:
+                    torch.cuda.current_stream().synchronize()       # the next call's update runs on another stream
         else:
             frames = self.shard.gather_frames_to_rank0(images)                # 'first' priority = frame order
             if self.shard.rank == 0:

@@ -250,7 +250,7 @@ class DiffusionRunner:
         return p["out"]
 
     def sample(self, noise, steps, sampler_name, scheduler, denoise=1.0, latent_image=None, seed=None,
-               inject_n_rand=None, step_callback=None, noise_fn=None):
+               inject_n_rand=None, step_callback=None, noise_fn=None, rng_turn=None):
         """-> samples (N,4,h,w) fp32 on device (already divided by the latent scale, samplers.py:933).
 
         RNG draw order on the *global CPU generator* replicates the reference: custom_ksampler's seed draw
@@ -260,27 +260,33 @@ class DiffusionRunner:
         sig = ks.sigmas
         sampler = ks.sampler_name
         dev = self.x.device
-        if seed is None:
-            seed = int(torch.randint(0, 2 ** 32, (1,)).item())
+        # rng_turn: context manager that admits concurrent callers in call order (pipeline.CallOrder) around the draws on the
+        # process-wide CPU generator, so calls in flight on several streams draw exactly what the sequential loop draws
+        import contextlib
+        with (rng_turn if rng_turn is not None else contextlib.nullcontext()):
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 32, (1,)).item())
+            if sampler == "ddim":
+                g = torch.manual_seed(seed + 1)
+                n_grp = noise.shape[0] if self.shard is None else self.shard.n_views     # the draw is over the WHOLE group
+                torch.randn((n_grp,) + tuple(noise.shape[1:]), generator=g, device="cpu")
+            inject = None
+            if inject_n_rand is not None and inject_n_rand >= 0:
+                n_all = self.N if self.shard is None else self.shard.n_views
+                B = n_all * self.copies
+                inject = torch.randint(1, B, (inject_n_rand,)).tolist()       # global RNG; B counts cond + uncond entries
+                if self.shard is not None and self.shard.world > 1:           # every rank must use rank 0's draw
+                    from . import parallel as PAR
+                    t_inj = torch.tensor(inject, dtype=torch.int64)
+                    PAR.broadcast(t_inj, 0, self.shard.group)
+                    inject = t_inj.tolist()
         latent = torch.zeros_like(noise) if latent_image is None else latent_image * LATENT_SCALE
-        if sampler == "ddim":
-            g = torch.manual_seed(seed + 1)
-            n_grp = noise.shape[0] if self.shard is None else self.shard.n_views     # the draw is over the WHOLE group
-            torch.randn((n_grp,) + tuple(noise.shape[1:]), generator=g, device="cpu")
         max_denoise = math.isclose(float(self.ms.sigma_max), float(sig[0]), rel_tol=1e-05) or float(sig[0]) > float(self.ms.sigma_max)
         s0 = float(torch.sqrt(1.0 + sig[0] ** 2.0)) if max_denoise else float(sig[0])
         self.x.copy_(noise.to(dev, torch.float32))
         O.axpby(self.x, latent.to(dev, torch.float32).contiguous(), 1.0, s0)        # x = noise*s0 + latent
-        inject = None
-        if inject_n_rand is not None and inject_n_rand >= 0:
-            n_all = self.N if self.shard is None else self.shard.n_views
-            B = n_all * self.copies
-            inject = torch.randint(1, B, (inject_n_rand,)).tolist()       # global RNG; B counts cond + uncond entries
-            if self.shard is not None and self.shard.world > 1:           # every rank must use rank 0's draw
-                from . import parallel as PAR
-                t_inj = torch.tensor(inject, dtype=torch.int64)
-                PAR.broadcast(t_inj, 0, self.shard.group)
-                inject = t_inj.tolist()
+        if rng_turn is not None and sampler in ("ddpm", "lcm"):
+            raise NotImplementedError("calls in flight draw per-step noise from the global generator with ddpm / lcm")
         p = self._ensure_plan(inject)
         self._load_ctx(p)
         if noise_fn is None:

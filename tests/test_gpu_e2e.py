@@ -223,3 +223,40 @@ def test_pipeline_with_gbuffer_driven_controlnets():
     assert float(hints[0].max()) > 0.0 and float((hints[0][:, 0] - hints[0][:, 1]).abs().max()) == 0.0   # depth repeated to 3 channels
     assert float((img - base).abs().max()) > 1e-4            # the residuals reach the UNet
     assert int(pipe.scene.corrmap._writtens.sum()) > 0
+
+
+def test_calls_in_flight_equal_the_sequential_loop(monkeypatch):
+    """pipeline.InflightCalls: two calls in flight (thread + stream + plans each, shared weights / scene / corr-map) bake the
+    same corr-map, frame for frame, as the plain loop: RNG draws and corr-map updates are taken in call order"""
+    from stable_renderer_amd.pipeline import build_sd15_pipeline, InflightCalls
+    from stable_renderer_amd.unet import SD15_CFG
+    monkeypatch.setenv("SR_AUTOTUNE", "0")
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    kw = dict(dtype=torch.float32, n_views=4, steps=3, cfg=5.0, W=128, H=128, unet_cfg=cfg, vae_ch=32)
+
+    def bake(inflight):
+        pipe = build_sd15_pipeline(**kw)
+        torch.manual_seed(77)
+        if inflight == 1:
+            for _ in range(5):
+                pipe.call()
+        else:
+            fl = InflightCalls(pipe, inflight)
+            assert fl.pipes[1].unet is pipe.unet and fl.pipes[1].scene is pipe.scene and fl.pipes[1].runner is not pipe.runner
+            fl.run(5)
+            assert all(p.frame0 == 20 for p in fl.pipes)
+        torch.cuda.synchronize()
+        cm = pipe.scene.corrmap
+        return cm._values.clone(), cm._writtens.clone(), torch.get_rng_state()
+    v1, w1, r1 = bake(1)
+    v2, w2, r2 = bake(2)
+
+    def same(va, vb):
+        # the overlap step accumulates with float atomics: two runs of the SAME sequential loop already differ by one fp16 ulp
+        # in ~0.15 % of the baked values (tools/check_inflight.py), so that is the bar here too
+        d = (va.float() - vb.float()).abs()
+        return float(d.max()) <= 2 ** -10 and int((d > 0).sum()) < 0.01 * d.numel()
+    assert int(w1.sum()) > 0 and torch.equal(w1, w2) and same(v1, v2)
+    assert torch.equal(r1, r2)                                  # the global generator ends in the same state
+    v3, w3, r3 = bake(3)
+    assert torch.equal(w1, w3) and same(v1, v3) and torch.equal(r1, r3)
