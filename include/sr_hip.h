@@ -76,7 +76,10 @@ typedef struct {
   const float* colsum;    /* [N] fp32, required with row_stats                                                     */
   int32_t tile;           /* 0 = library heuristic; 1 = 256x128 (8 waves, 3-stage), 2 = 128x128, 3 = 128x64, 4 = 64x64,
                              5 = 256x320 (fp16, N % 320 == 0; 2 LDS stages of 128-byte K-steps), 6 = 256x320 with a 4-deep ring of
-                             64-byte K-steps, 7 = 128x320 (8 waves, for half as many pixels).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
+                             64-byte K-steps, 7 = 128x320 (8 waves, for half as many pixels), 8 = patch-stationary 3x3 (256x320; fp16, KH 3,
+                             stride 1, one source, N % 320 == 0, M % 256 == 0, 256-pixel tiles = whole image rows or whole 8x8
+                             images: the activation halo is staged once per 32-channel chunk and the nine taps read it at nine LDS
+                             offsets; SR_ERR_INVALID otherwise).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
   int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split                      */
 } sr_igemm_args;
 int sr_igemm(const sr_igemm_args* args, void* stream);

@@ -17,6 +17,7 @@
 // transpose_out the roles swap and a lane holds 4 consecutive pixels of one channel (V^T for attention).
 #include "sr_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -567,6 +568,177 @@ int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int tile0, int S
   return SR_OK;
 }
 
+// ---- patch-stationary 3x3 convolution (tile 8): 256 x 320, 8 waves ------------------------------------------------------
+// The implicit GEMM above re-stages the activation tile for each of the nine filter taps (PMC: 375 MB fetched per launch of
+// the 64x64 C320 conv against 43.8 MB of input).  Here a workgroup's 256 output pixels are whole image rows (or whole 8x8
+// images), so the pixels any tap needs are the tile's own rows plus a one-pixel halo: that halo patch is staged ONCE per
+// 32-channel chunk and the nine taps read it at nine LDS offsets.  Per chunk and workgroup 32 KB of activations + 9 x 20 KB of
+// weights go through the 64 B/clk TCP->LDS path instead of 9 x (16 + 20) KB.
+//   LDS: activation halo, double buffered, pitch 80 B (64 B of channels + 16 B pad: 16 consecutive rows fall on 16 distinct
+//   16-byte bank groups, so a tap shift is a plain address offset with no swizzle to re-derive); weight stages in a 4-slot
+//   ring of 64-byte K-steps (the BKB = 64 layout of igemm_kernel).  2 x 32 KB + 4 x 20 KB = 144 KB.
+//   Pipeline: step s = (chunk c, tap t); weights run three steps ahead, the four halo pieces of chunk c+1 are issued at taps
+//   0..3 of chunk c; all LDS-DMA from inline asm with counted vmcnt (the count per tap is a compile-time constant because the
+//   tap loop is unrolled).
+__global__ __launch_bounds__(512, 1) void conv3p_kernel(const sr_igemm_args p, const int M, const int NT, const int nwg) {
+  using T = _Float16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 320, WAVES_M = 4, WAVES_N = 2, TM = 4, TN = 10;
+  constexpr int APITCH = 80, ABYTES = 32768, BBYTES = BN * 64, BOFF = 2 * ABYTES, LDS_TOTAL = BOFF + 4 * BBYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = sr_xcd_remap(blockIdx.x, nwg);
+  const int mt = wg / NT, nt = wg - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int H = p.H, W = p.W, C1 = p.C1, rpb = H * W;
+  const int ipt = rpb >= 256 ? 1 : 256 / rpb;          // images per tile
+  const int Ri = rpb >= 256 ? 256 / W : H;             // image rows (per image) in the tile
+  const int PW = W + 2, HPI = (Ri + 2) * PW, HR = ipt * HPI;
+  const int b0 = m0 / rpb, y0 = (m0 - b0 * rpb) / W;
+
+  // ---- halo pieces: LDS-DMA instruction k = wv*4 + i fills the 64 sixteen-byte slots [k*64, k*64+64) of the halo buffer.
+  // Slots outside the image (and the pad chunk of every row) are the same for every channel chunk: they are zeroed once in
+  // both buffers and the LDS-DMA runs with those lanes masked off.  Sources are 32-bit offsets from a wave-uniform base
+  // (SGPR pair) that advances by 64 bytes per chunk: one VGPR per piece.
+  unsigned aoffg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = (wv * 4 + i) * 64 + lane;           // slot -> (halo row, 16-B chunk; chunk 4 is the pad)
+    const int hrow = u / 5, ch = u - hrow * 5;
+    const int img = hrow / HPI, rem = hrow - img * HPI, hr = rem / PW, hc = rem - hr * PW;
+    const int y = y0 + hr - 1, x = hc - 1, b = b0 + img;
+    const bool ok = ch < 4 && hrow < HR && y >= 0 && y < H && x >= 0 && x < W && b < p.B;
+    aoffg[i] = ok ? (unsigned)(((((int64_t)b * H + y) * W + x) * C1) * 2 + ch * 16) : 0xFFFFFFFFu;
+    if (!ok) {
+      *(uint4*)(smem + (wv * 4 + i) * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+      *(uint4*)(smem + ABYTES + (wv * 4 + i) * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill is in LDS before this wave's first barrier
+  // ---- weight rows (64-byte K-steps: 16 rows per instruction, source-side swizzle as in igemm_kernel): the per-lane part
+  // (row within the 16-row group, chunk) is the same for the three instructions of a stage, the group is wave-uniform
+  const int lrow = lane >> 2;
+  const int lchunk = (0x1320 >> (4 * ((lane & 3) ^ ((lrow >> 2) & 3)))) & 3;
+  const unsigned wlane = (unsigned)(lrow * 9 * C1 * 2 + lchunk * 16);
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane(sr_lds_addr(smem)), ldsB = ldsA + BOFF;
+  int ac = 0;                                           // halo chunk cursor
+  auto issueA = [&](int buf, int i) {
+    if (aoffg[i] != 0xFFFFFFFFu) sr_glds16_asm_saddr(aoffg[i], (const char*)p.a + (int64_t)ac * 64, ldsA + buf * ABYTES + (wv * 4 + i) * 1024);
+  };
+  int lc = 0, lt = 0;                                   // load cursor (chunk, tap) of the next weight stage
+  auto issueB = [&](int slot) {
+    const char* wb = (const char*)p.w + ((int64_t)n0 * 9 * C1 + lt * C1 + lc * 32) * 2;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int gi = (i * 8 + wv) < 20 ? (i * 8 + wv) : 19;
+      sr_glds16_asm_saddr(wlane, wb + (int64_t)gi * 16 * 9 * C1 * 2, ldsB + slot * BBYTES + gi * 1024);
+    }
+    if (++lt == 9) { lt = 0; ++lc; }
+  };
+
+  // ---- fragment offsets
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int pm0 = wm * 64, qn0 = wn * 160;
+  // fragment rows of the wave's four 16-pixel groups: per-lane base + wave-uniform deltas (16 | W, or two 8-pixel rows)
+  int aoff0, adel[TM];
+  {
+    const int riw = Ri * W;
+    auto hrow_of = [&](int pi) { const int img = pi / riw, q = pi - img * riw, r = q / W, cx = q - r * W; return img * HPI + r * PW + cx; };
+    aoff0 = hrow_of(pm0 + c16) * APITCH + g4 * 16;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) adel[j] = __builtin_amdgcn_readfirstlane((hrow_of(pm0 + j * 16) - hrow_of(pm0)) * APITCH);
+  }
+  const int foffB = qn0 * 64 + c16 * 64 + ((((c16 >> 2) & 3) ^ ((0x2130 >> (4 * g4)) & 3)) << 4);
+  const int pw80 = PW * APITCH;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int NC = C1 / 32;
+  {
+    const unsigned m0k = sr_m0_save();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issueA(0, i);
+    ac = 1;
+    issueB(0); issueB(1); issueB(2);
+    sr_m0_restore(m0k);
+  }
+  // One barrier per step (one tap of one chunk): wait for this wave's pieces of weight stage s, barrier, start the 14 fragment
+  // reads, issue the stage three steps ahead (+ a halo piece) behind them, 40 MFMAs.
+  // Measured alternatives on the 64x64 C320 conv (this form: 118 us; the re-staging 256x320 tile: 124 us): two taps per
+  // barrier with one pair of stages in flight 126 us (prefetch depth matters more than barrier count); ping-pong of the two
+  // waves of each SIMD (memory phase | barrier | MFMA phase, waves 4..7 half a step late) 137 us, and 163 us with the groups
+  // chosen so that both waves of a SIMD share a phase (which shows waves w and w+4 share a SIMD, and that the second barrier
+  // and the drained fragment reads cost more than the overlap returns: the 112 KB of fragment reads per step are ~70 % of the
+  // step's MFMA time on this tile and already overlap the MFMAs within a wave).
+  int s = 0;
+  auto chunk = [&](auto lastc, const int c) {
+    constexpr bool LASTC = decltype(lastc)::value;
+    auto step = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      // this wave's LDS-DMA instructions younger than weight stage s: stages s+1, s+2 and the halo pieces issued at taps 0..3
+      // among the last three steps (unrolled taps -> compile-time counts)
+      constexpr int nx = LASTC ? (t <= 6 ? 6 : (t == 7 ? 3 : 0))
+                               : 6 + (t >= 1 && t <= 4) + (t >= 2 && t <= 5) + (t >= 3 && t <= 6);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nx) : "memory");
+      __builtin_amdgcn_s_barrier();                       // stage s (at t == 0 also the halo of chunk c) visible; step s-1 done
+      const char* Bq = smem + BOFF + (s & 3) * BBYTES + foffB;
+      // (opaque to the optimiser: otherwise the 9 x 4 loop-invariant fragment addresses are hoisted out of the chunk loop into
+      //  VGPRs the kernel does not have, and their reloads from scratch carry s_waitcnt vmcnt(0) into the main loop)
+      int to = (t / 3) * pw80 + (t % 3) * APITCH + (c & 1) * ABYTES;
+      asm volatile("" : "+s"(to));
+      uint4 xf[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *(const uint4*)(smem + aoff0 + (adel[j] + to));
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) wf[tn] = *(const uint4*)(Bq + tn * 1024);
+      if (!LASTC || t < 6) {
+        const unsigned m0k = sr_m0_save();
+        issueB((s + 3) & 3);
+        if constexpr (!LASTC) { if (t < 4) issueA((c + 1) & 1, t); if (t == 3) ++ac; }
+        sr_m0_restore(m0k);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) sr_mma(acc[tn][tm], wf[tn], xf[tm], T());
+      ++s;
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+  };
+  for (int c = 0; c < NC - 1; ++c) chunk(std::false_type{}, c);
+  chunk(std::true_type{}, NC - 1);
+
+  epilogue_rows<T, BM, BN, WAVES_M, WAVES_N, LDS_TOTAL>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
+}
+
+static bool conv3p_ok(const sr_igemm_args& a, int M) {
+  if (a.dtype != SR_F16 || a.KH != 3 || a.stride != 1 || a.upsample || a.C2 || a.transpose_out || a.row_stats) return false;
+  if (a.C1 % 64 || a.N % 320 || M % 256 || a.act == 2) return false;
+  const int rpb = a.H * a.W;
+  if (a.W < 8 || 256 % a.W) { if (!(rpb < 256 && 256 % rpb == 0)) return false; }
+  if (rpb >= 256 ? (rpb % 256 != 0 || 256 % a.W != 0) : (256 % rpb != 0)) return false;
+  const int ipt = rpb >= 256 ? 1 : 256 / rpb, Ri = rpb >= 256 ? 256 / a.W : a.H;
+  if ((int64_t)a.B * rpb * a.C1 * 2 >= 0xFFFFFFFFLL) return false;          // 32-bit source offsets
+  return ipt * (Ri + 2) * (a.W + 2) * 80 <= 32768;
+}
+
+static int launch_conv3p(const sr_igemm_args& a, int M, hipStream_t st) {
+  constexpr int lds = 2 * 32768 + 4 * 320 * 64;
+  const int NT = a.N / 320, nwg = (M / 256) * NT;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  hipLaunchKernelGGL(conv3p_kernel, dim3(nwg), dim3(512), lds, st, a, M, NT, nwg);
+  SR_CHECK_LAUNCH("sr_igemm(conv3p)");
+  return SR_OK;
+}
+
 // Wave quantisation model for the 4-wave tiles (calibrated on MI355X): `slots` workgroups are co-resident
 // chip-wide, a round of co-resident workgroups takes t_k microseconds per K-step, partials cost their HBM round trip.
 // Returns the split count for the tail round (1 = none) and sets tile0 (tiles before it run unsplit).
@@ -614,6 +786,11 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   if (force == 2) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 3) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 4) return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if (force == 8) {
+    if constexpr (!TRANS && sizeof(T) == 2) { if (conv3p_ok(a, M)) return launch_conv3p(a, M, st); }
+    SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 8 (patch-stationary 3x3) needs fp16, KH=3, stride 1, one source, N %% 320 == 0, "
+                            "256-pixel tiles of whole rows / images (H=%d W=%d M=%d N=%d)", a.H, a.W, M, a.N);
+  }
   if constexpr (!TRANS && sizeof(T) == 2) {
     // (4-wave 128x128 / 128x64 tiles with a 4-deep ring of 64-byte K-steps measured 5..30 % slower than their 2 x 128-byte
     //  form on every UNet shape: twice the barriers per K, and those tiles already overlap through co-resident workgroups)
@@ -688,7 +865,7 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
   if (a->row_stats && !a->colsum) SR_FAIL(SR_ERR_INVALID, "sr_igemm: row_stats without colsum");
   if (a->row_stats && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
-  if (a->tile < 0 || a->tile > 7 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
+  if (a->tile < 0 || a->tile > 8 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }
   else if (a->stride == 2) { Ho = (a->H + 2 * (a->KH / 2) - a->KH) / 2 + 1; Wo = (a->W + 2 * (a->KH / 2) - a->KH) / 2 + 1; }

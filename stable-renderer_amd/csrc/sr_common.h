@@ -62,6 +62,10 @@ __device__ __forceinline__ void sr_m0_restore(unsigned keep) { asm volatile("s_m
 __device__ __forceinline__ void sr_glds16_asm_nosave(const void* gsrc, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory");
 }
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: one VGPR per stream instead of two
+__device__ __forceinline__ void sr_glds16_asm_saddr(unsigned voff, const void* sbase, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
 __device__ __forceinline__ unsigned sr_lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }

@@ -172,6 +172,44 @@ def test_igemm_forced_tiles(ops, tile, act):
     close(got, ref, dtype, scale=ref.abs().max().item())
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 128, 320), (4, 32, 32, 192, 640), (5, 16, 16, 64, 320), (8, 8, 8, 256, 320),
+                                   (1, 64, 64, 64, 320), (2, 16, 32, 128, 320)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_igemm_patch_stationary_conv3(ops, shape, act):
+    """tile 8: the patch-stationary 3x3 convolution (halo staged once per 32-channel chunk, nine taps as LDS offsets) on every
+    map width it serves -- 64 (4 image rows per tile), 32 (8 rows), 16 (one image), 8 (four images) -- image borders, tile
+    borders inside an image, bias + time-embedding slice + residual / SiLU, and its rejection of shapes it cannot tile"""
+    dtype, dev = torch.float16, "cuda"
+    B, H, W, C1, N = shape
+    x = rnd(1, B, C1, H, W)
+    w = rnd(2, N, C1, 3, 3) * (C1 * 9) ** -0.5
+    bias, rowvec, resid = rnd(3, N) * 0.1, rnd(4, B, N), rnd(5, B, N, H, W)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), bias, padding=1) + rowvec[:, :, None, None]
+    if act == 1:
+        ref = F.silu(ref)
+    ref = ref + resid.to(dtype).float()
+    M = B * H * W
+    xa = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    wp, bp = ops.pack_conv_weight(w, dtype).to(dev), ops.pack_bias(bias).to(dev)
+    rs = resid.permute(0, 2, 3, 1).reshape(M, N).contiguous().to(dtype).to(dev)
+    out = torch.zeros(M, N, dtype=dtype, device=dev)
+    ops.igemm(xa, wp, out, B, H, W, C1, N, KH=3, bias=bp, rowvec=rowvec.contiguous().to(dev), residual=rs, act=act, tile=8, split=-1)
+    torch.cuda.synchronize()
+    got = out.float().cpu().reshape(B, H, W, N).permute(0, 3, 1, 2)
+    close(got, ref, dtype, scale=ref.abs().max().item())
+    if shape == (2, 64, 64, 128, 320) and act == 0:
+        base = torch.zeros_like(out)                            # same operands through the re-staging 256x320 tile
+        ops.igemm(xa, wp, base, B, H, W, C1, N, KH=3, bias=bp, rowvec=rowvec.contiguous().to(dev), residual=rs, act=act, tile=5, split=-1)
+        assert float((base.float() - out.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+        from stable_renderer_amd import _lib as L
+        for bad in (dict(N=640, H=24, W=20), dict(N=256, H=64, W=64)):      # ragged map / N not a multiple of 320
+            with pytest.raises(L.SrHipError):
+                o2 = torch.zeros(2 * bad["H"] * bad["W"], bad["N"], dtype=dtype, device=dev)
+                x2 = torch.zeros(2, bad["H"], bad["W"], C1, dtype=dtype, device=dev)
+                w2 = ops.pack_conv_weight(torch.zeros(bad["N"], C1, 3, 3), dtype).to(dev)
+                ops.igemm(x2, w2, o2, 2, bad["H"], bad["W"], C1, bad["N"], KH=3, tile=8, split=-1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mode", ["plain", "geglu", "transposed", "residual_big"])
 def test_igemm_folded_layernorm(ops, dtype, mode):

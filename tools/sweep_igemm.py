@@ -23,7 +23,7 @@ def run(B, H, W, C, N, KH, act=0, reps=20):
     ms = e0.elapsed_time(e1) / reps
     return ms * 1e3, 2.0 * B * H * W * N * KH * KH * C / ms / 1e9
 
-TILES = (0, 1, 2, 3, 4)
+TILES = tuple(int(v) for v in os.environ.get("SWEEP_TILES", "0,1,2,3,4").split(","))
 shapes = [
     (65536, 1, 1, 64, 320, 1, 0), (65536, 1, 1, 320, 320, 1, 0), (65536, 1, 1, 640, 320, 1, 0), (65536, 1, 1, 1280, 320, 1, 0),
     (16384, 1, 1, 640, 640, 1, 0), (4096, 1, 1, 1280, 1280, 1, 0),
@@ -31,7 +31,7 @@ shapes = [
     (65536, 1, 1, 320, 2560, 1, 0),
     (16, 8, 8, 1280, 1280, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 32, 32, 640, 640, 3, 0), (16, 64, 64, 320, 320, 3, 0),
 ]
-if len(sys.argv) > 1 and sys.argv[1] not in ("splitk", "t5", "t78", "vae", "splits"):
+if len(sys.argv) > 1 and sys.argv[1] not in ("splitk", "t5", "t78", "vae", "splits", "conv3p"):
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 if len(sys.argv) > 1 and sys.argv[1] == "t5":
     TILES = (0, 1, 2, 3, 5, 7)
@@ -46,6 +46,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "t78":
     shapes = [(16384, 1, 1, 640, 640, 1, 0), (4096, 1, 1, 1280, 1280, 1, 0), (4096, 1, 1, 5120, 1280, 1, 0), (16384, 1, 1, 2560, 640, 1, 0),
               (16, 32, 32, 640, 640, 3, 0), (16, 32, 32, 1280, 640, 3, 0), (16, 16, 16, 1280, 1280, 3, 0), (16, 8, 8, 1280, 1280, 3, 0),
               (65536, 1, 1, 320, 320, 1, 0), (16384, 1, 1, 640, 5120, 1, 2), (4096, 1, 1, 1280, 10240, 1, 2)]
+if len(sys.argv) > 1 and sys.argv[1] == "conv3p":          # patch-stationary 3x3 (tile 8) against the re-staging tiles
+    TILES = (5, 8, 6, 7, 1, 8, 5)
+    shapes = [(16, 64, 64, 320, 320, 3, 0), (16, 64, 64, 640, 320, 3, 0), (16, 64, 64, 960, 320, 3, 0), (16, 32, 32, 320, 640, 3, 0),
+              (16, 32, 32, 640, 640, 3, 0), (16, 32, 32, 1280, 640, 3, 0), (16, 32, 32, 960, 640, 3, 0), (16, 16, 16, 640, 1280, 3, 0),
+              (16, 16, 16, 1280, 1280, 3, 0), (16, 16, 16, 2560, 1280, 3, 0), (16, 8, 8, 1280, 1280, 3, 0), (16, 8, 8, 2560, 1280, 3, 0),
+              (16, 64, 64, 1280, 1280, 3, 0)]
 if len(sys.argv) > 1 and sys.argv[1] == "vae":
     TILES = (0, 1, 2, 8)
     shapes = [(8, 512, 512, 128, 128, 3, 0), (8, 256, 256, 256, 256, 3, 0), (8, 128, 128, 512, 512, 3, 0), (8, 512, 512, 256, 128, 3, 0),
