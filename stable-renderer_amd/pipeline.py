@@ -121,6 +121,7 @@ class InflightCalls:
         def work(i):
             p, st = self.pipes[i], self.streams[i]
             try:
+                torch.cuda.set_device(st.device)            # the current device is per thread (rank r works on GPU r)
                 with torch.cuda.stream(st), O.workspace_slot(i):
                     for c in range(i, n_calls, len(self.pipes)):
                         p.frame0 = base + c * p.N_all
