@@ -79,7 +79,8 @@ typedef struct {
                              64-byte K-steps, 7 = 128x320 (8 waves, for half as many pixels), 8 = patch-stationary 3x3 (256x320; fp16, KH 3,
                              stride 1, one source, N % 320 == 0, M % 256 == 0, 256-pixel tiles = whole image rows or whole 8x8
                              images: the activation halo is staged once per 32-channel chunk and the nine taps read it at nine LDS
-                             offsets; SR_ERR_INVALID otherwise).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
+                             offsets; SR_ERR_INVALID otherwise), 9 = 128x160 and 10 = 128x320 with 64-byte K-steps (fp16; two co-resident
+                             workgroups per CU for the K-short linear layers).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
   int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split                      */
 } sr_igemm_args;
 int sr_igemm(const sr_igemm_args* args, void* stream);

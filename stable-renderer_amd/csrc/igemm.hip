@@ -800,6 +800,21 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // measured 830 vs 627 TF/s on the 64x64 C320 3x3 conv, 1086 vs 1000 on C1280, but 556 vs 678 at 32x32 C640.
     if ((force >= 5 && force <= 7) && a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d (256x320) needs N %% 320 == 0, N=%d", force, a.N);
     if (force == 6) return launch<T, 256, 320, 4, 2, 4, TRANS, 64>(a, M, Ho, Wo, st);
+    // Two co-resident workgroups per CU for the K-short linear layers (to_q / to_out / proj_in / proj_out, GEGLU: K = 320..1280,
+    // 30 launches each per UNet evaluation): with one 8-wave workgroup per CU every workgroup of the single round loads, computes
+    // and stores in the same phase, so HBM reads, MFMA and HBM writes never overlap; two workgroups (<= 80 KB LDS, <= 128 VGPRs
+    // each) drift apart and overlap them.  9 = 128x160 (8 waves of 32x80, 74 KB, 92 VGPRs): 29.5 vs 36.2 us at M65536 K320
+    // N320, 23.3 vs 25.1 at M16384 K640 N640, 24.3 vs 26.6 at M4096 K1280 N1280, 233 vs 263 us on the 64x64 GEGLU.
+    // 10 = 128x320 with 64-byte K-steps (57 KB; reads the activation tile once for N = 320): 28.8 us on the first, 174-180 us
+    // on the 32x32 GEGLU.  (A 3-slot ring of 64-byte K-steps under the 128x160 tile measured 5..10 % behind the 2 x 128-byte form.)
+    if (force == 9) {
+      if (a.N % 160) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 9 (128x160) needs N %% 160 == 0, N=%d", a.N);
+      return launch<T, 128, 160, 4, 2, 2, TRANS, 128, 0, 2>(a, M, Ho, Wo, st);
+    }
+    if (force == 10) {
+      if (a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 10 (128x320) needs N %% 320 == 0, N=%d", a.N);
+      return launch<T, 128, 320, 2, 4, 2, TRANS, 64, 0, 4>(a, M, Ho, Wo, st);
+    }
     // 128x320 (8 waves as 2x4, 64x80 per wave, 112 KB): the same full-width rows for layers with half as many pixels -- the
     // 32x32 level (M = 16384, N = 640) gets exactly one round of 256 workgroups: 130 vs 161 us on its 3x3 conv (926 TF/s),
     // 61 vs 80 us on the K = 2560 linear.  (A 64x320 tile for the 16x16 level measured no better than split-K 128x128.)
@@ -865,7 +880,7 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
   if (a->row_stats && !a->colsum) SR_FAIL(SR_ERR_INVALID, "sr_igemm: row_stats without colsum");
   if (a->row_stats && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
-  if (a->tile < 0 || a->tile > 8 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
+  if (a->tile < 0 || a->tile > 10 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }
   else if (a->stride == 2) { Ho = (a->H + 2 * (a->KH / 2) - a->KH) / 2 + 1; Wo = (a->W + 2 * (a->KH / 2) - a->KH) / 2 + 1; }
