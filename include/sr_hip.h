@@ -80,7 +80,8 @@ typedef struct {
                              stride 1, one source, N % 320 == 0, M % 256 == 0, 256-pixel tiles = whole image rows or whole 8x8
                              images: the activation halo is staged once per 32-channel chunk and the nine taps read it at nine LDS
                              offsets; SR_ERR_INVALID otherwise), 9 = 128x160 and 10 = 128x320 with 64-byte K-steps (fp16; two co-resident
-                             workgroups per CU for the K-short linear layers).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
+                             workgroups per CU for the K-short linear layers), 11 = 128x128 as 8 waves and 12 = 256x128 with 64-byte K-steps
+                             (fp16; the same for widths that are multiples of 128 only).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
   int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split                      */
 } sr_igemm_args;
 int sr_igemm(const sr_igemm_args* args, void* stream);

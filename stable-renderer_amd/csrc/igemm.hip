@@ -815,6 +815,11 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
       if (a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 10 (128x320) needs N %% 320 == 0, N=%d", a.N);
       return launch<T, 128, 320, 2, 4, 2, TRANS, 64, 0, 4>(a, M, Ho, Wo, st);
     }
+    // the same idea for layer widths that are multiples of 128 but not of 160 (the VAE decoder): 11 = 128x128 as 8 waves of
+    // 32x64 (64 KB), 12 = 256x128 with 64-byte K-steps (49 KB).  844 vs 899 us on the 512x512 C128 conv, 369 vs 457 us on the
+    // 2M-row C256 -> 128 1x1 layer; level with the 4-wave / 3-stage forms elsewhere -- the tuner decides per shape.
+    if (force == 11) return launch<T, 128, 128, 4, 2, 2, TRANS, 128, 0, 4>(a, M, Ho, Wo, st);
+    if (force == 12) return launch<T, 256, 128, 4, 2, 2, TRANS, 64, 0, 4>(a, M, Ho, Wo, st);
     // 128x320 (8 waves as 2x4, 64x80 per wave, 112 KB): the same full-width rows for layers with half as many pixels -- the
     // 32x32 level (M = 16384, N = 640) gets exactly one round of 256 workgroups: 130 vs 161 us on its 3x3 conv (926 TF/s),
     // 61 vs 80 us on the K = 2560 linear.  (A 64x320 tile for the 16x16 level measured no better than split-K 128x128.)
@@ -880,7 +885,7 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
   if (a->row_stats && !a->colsum) SR_FAIL(SR_ERR_INVALID, "sr_igemm: row_stats without colsum");
   if (a->row_stats && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
-  if (a->tile < 0 || a->tile > 10 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
+  if (a->tile < 0 || a->tile > 12 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }
   else if (a->stride == 2) { Ho = (a->H + 2 * (a->KH / 2) - a->KH) / 2 + 1; Wo = (a->W + 2 * (a->KH / 2) - a->KH) / 2 + 1; }

@@ -118,7 +118,7 @@ if _TUNE_CACHE and os.path.exists(_TUNE_CACHE):
     import json as _json
     with open(_TUNE_CACHE) as _f:
         _TUNED.update({tuple(_json.loads(k)): tuple(v) for k, v in _json.load(_f).items()})
-_CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (3, 0), (3, -1), (4, -1), (5, -1), (6, -1), (7, -1), (8, -1), (9, -1), (10, -1))
+_CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (3, 0), (3, -1), (4, -1), (5, -1), (6, -1), (7, -1), (8, -1), (9, -1), (10, -1), (11, -1), (12, -1))
 
 
 def autotune_enabled():

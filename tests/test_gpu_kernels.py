@@ -136,7 +136,7 @@ def test_igemm(ops, dtype, case):
     close(got, ref, dtype, scale=ref.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 9, 10])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12])
 @pytest.mark.parametrize("act", [0, 2])
 def test_igemm_forced_tiles(ops, tile, act):
     """every tile configuration the tuner may pin (sr_igemm_args.tile), incl. the 256x320 tiles with 2 x 128-byte and
