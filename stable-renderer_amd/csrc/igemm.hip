@@ -818,6 +818,9 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // the same idea for layer widths that are multiples of 128 but not of 160 (the VAE decoder): 11 = 128x128 as 8 waves of
     // 32x64 (64 KB), 12 = 256x128 with 64-byte K-steps (49 KB).  844 vs 899 us on the 512x512 C128 conv, 369 vs 457 us on the
     // 2M-row C256 -> 128 1x1 layer; level with the 4-wave / 3-stage forms elsewhere -- the tuner decides per shape.
+    // (3- and 4-deep rings under the 128x160 tile change nothing on the K-long few-tile layers -- 24.4 us at M4096 K1280 N1280
+    //  either way: with 128x160 tiles that layer moves 191 MB from L2 to the CUs, i.e. it runs at the L2 read bandwidth -- and
+    //  lose 25 % where two workgroups per CU mattered)
     if (force == 11) return launch<T, 128, 128, 4, 2, 2, TRANS, 128, 0, 4>(a, M, Ho, Wo, st);
     if (force == 12) return launch<T, 256, 128, 4, 2, 2, TRANS, 64, 0, 4>(a, M, Ho, Wo, st);
     // 128x320 (8 waves as 2x4, 64x80 per wave, 112 KB): the same full-width rows for layers with half as many pixels -- the
