@@ -152,7 +152,7 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         peak = 2500.0 if a.dtype == "f16" else 157.3
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all %d launches of one UNet eval, B=%d)" % (sub.n, a.views * 2),
+        roof = {"bound": "mfma", "kernel": "igemm family: igemm_kernel tiles + conv3p_kernel (implicit-GEMM conv/linear, all %d launches of one UNet eval, B=%d)" % (sub.n, a.views * 2),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launches": sub.n, "avg_launch_us": round(ms * 1e3 / max(sub.n, 1), 2), "flops_per_eval": flops}
         full = pipe.runner._plan["flops"]

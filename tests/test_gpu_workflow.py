@@ -100,6 +100,28 @@ def test_shipped_graph_equals_direct_node_calls(graph, monkeypatch):
     assert torch.equal(vals, ed2.correspond_maps[(1, 1)]._values) and written == int(ed2.correspond_maps[(1, 1)]._writtens.sum())
 
 
+@pytest.mark.parametrize("graph", ["miku-control", "no-normal-bake", "no-mask-prompt-bake"])
+def test_other_shipped_graphs_run(graph, monkeypatch):
+    """the remaining loadable example graphs: KSampler + lcm sampler with a seed and two ControlNets (miku-control), one ControlNet
+    (no-normal-bake), plain CLIPTextEncode prompts (no-mask-prompt-bake); twice with the same inputs -> the same frames"""
+    from stable_renderer_amd import workflow as W
+    _register(monkeypatch)
+    outs = []
+    for _ in range(2):
+        ed = _engine_data(7)
+        ex = W.PromptExecutor(dev_mode=True)
+        torch.manual_seed(5)
+        ctx = W.run_workflow(os.path.join(WF, graph + ".json"), engine_data=ed, executor=ex)
+        assert ctx.success
+        img = ctx.final_output.frame_color.clone()
+        assert tuple(img.shape) == (2, H, W_, 3) and bool(torch.isfinite(img).all()) and float(img.std()) > 0
+        assert float(img.min()) >= 0 and float(img.max()) <= 1
+        written = int(ed.correspond_maps[(1, 1)]._writtens.sum())
+        assert (written > 0) == (graph != "miku-control")          # only the CorrespondSampler graphs carry the bake callback
+        outs.append(img)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_loaders_are_cached_across_frames(monkeypatch):
     from stable_renderer_amd import workflow as W
     _register(monkeypatch)
