@@ -4,7 +4,6 @@ No window, no GLFW, no input: the stage loop is rasterise -> (every ``baking_int
 Frame -> pose is deterministic (``EqualIntervalRotation``: 360/interval degrees per frame) instead of wall-clock driven
 (SURVEY.md App. A).  Only what the hot path needs is modelled; kwargs of the reference that concern the window / UI are
 accepted and ignored."""
-import math
 from enum import Enum
 from typing import List, Optional
 

@@ -11,7 +11,6 @@ This is the body of the reference's bake call (DiffusionManager.SubmitPrompt wit
 diffusionManager.py:289-352) for a scene of the ``scripts/bake_ball.py`` kind; all stages stay in HBM."""
 import contextlib
 import copy
-import math
 import threading
 
 import torch

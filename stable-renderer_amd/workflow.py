@@ -18,7 +18,7 @@ import sys
 import traceback
 import typing
 import uuid
-from typing import Any, Dict, List, Optional
+from typing import Dict, List, Optional
 
 from .types import EngineData, InferenceOutput
 
