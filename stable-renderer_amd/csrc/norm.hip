@@ -64,7 +64,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x1,
       const int c0 = cc * EPC;
       const T* src = c0 < C1 ? x1 + (int64_t)b * HW * C1 + c0 : x2 + (int64_t)b * HW * C2 + (c0 - C1);
       const int cs = c0 < C1 ? C1 : C2;
-      for (int p = p0 + ps; p < p1; p += pp) {
+      // four pixels per trip: four independent 16-byte loads in flight per lane (the walk is otherwise one load, a dependent
+      // accumulate, the next load); the accumulation order per lane is unchanged, so results are too
+      int p = p0 + ps;
+      for (; p + 3 * pp < p1; p += 4 * pp) {
+        float v0[EPC], v1[EPC], v2[EPC], v3[EPC];
+        load_chunk<T>(src + (int64_t)p * cs, v0);
+        load_chunk<T>(src + (int64_t)(p + pp) * cs, v1);
+        load_chunk<T>(src + (int64_t)(p + 2 * pp) * cs, v2);
+        load_chunk<T>(src + (int64_t)(p + 3 * pp) * cs, v3);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          s[e] += v0[e]; q[e] += v0[e] * v0[e];
+          s[e] += v1[e]; q[e] += v1[e] * v1[e];
+          s[e] += v2[e]; q[e] += v2[e] * v2[e];
+          s[e] += v3[e]; q[e] += v3[e] * v3[e];
+        }
+      }
+      for (; p < p1; p += pp) {
         float v[EPC];
         load_chunk<T>(src + (int64_t)p * cs, v);
 #pragma unroll
@@ -147,18 +164,34 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
   const int p0 = chunk * ppc;
   const int p1 = min(HW, p0 + ppc);
   const int total = (p1 - p0) * cpt;
-  for (int idx = tid; idx < total; idx += 256) {
-    const int p = p0 + idx / cpt, cc = idx - (idx / cpt) * cpt;
-    const int c0 = cc * EPC;
-    const T* src = c0 < C1 ? x1 + ((int64_t)b * HW + p) * C1 + c0 : x2 + ((int64_t)b * HW + p) * C2 + (c0 - C1);
-    float v[EPC];
-    load_chunk<T>(src, v);
+  auto src_of = [&](int idx, int& c0, int& p) -> const T* {
+    p = p0 + idx / cpt;
+    c0 = (idx - (idx / cpt) * cpt) * EPC;
+    return c0 < C1 ? x1 + ((int64_t)b * HW + p) * C1 + c0 : x2 + ((int64_t)b * HW + p) * C2 + (c0 - C1);
+  };
+  auto finish = [&](float (&v)[EPC], int c0, int p) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float t = v[e] * sc[c0 + e] + sh[c0 + e];
       v[e] = silu ? sr_silu_f(t) : t;
     }
     store_chunk<T>(y + ((int64_t)b * HW + p) * C + c0, v);
+  };
+  int idx = tid;
+  for (; idx + 3 * 256 < total; idx += 4 * 256) {          // four 16-byte loads in flight per lane
+    int c0[4], pq[4];
+    float v0[EPC], v1[EPC], v2[EPC], v3[EPC];
+    load_chunk<T>(src_of(idx, c0[0], pq[0]), v0);
+    load_chunk<T>(src_of(idx + 256, c0[1], pq[1]), v1);
+    load_chunk<T>(src_of(idx + 512, c0[2], pq[2]), v2);
+    load_chunk<T>(src_of(idx + 768, c0[3], pq[3]), v3);
+    finish(v0, c0[0], pq[0]); finish(v1, c0[1], pq[1]); finish(v2, c0[2], pq[2]); finish(v3, c0[3], pq[3]);
+  }
+  for (; idx < total; idx += 256) {
+    int c0, pq;
+    float v[EPC];
+    load_chunk<T>(src_of(idx, c0, pq), v);
+    finish(v, c0, pq);
   }
 }
 
