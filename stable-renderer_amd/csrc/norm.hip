@@ -333,53 +333,75 @@ bool try_gn_fused(const sr_groupnorm_args* a, hipStream_t st) {
 }
 
 // one wave per row
-template <typename T>
+// One wave per ROWS consecutive rows (MAXC 16-byte chunks per lane and row): with one 640-byte row per wave the kernel is a chain
+// load -> two shuffle trees -> store with ~20 KB in flight per CU (3.2 TB/s at rows 65536, C 320); ROWS independent rows per
+// wave put ROWS times as many loads in flight.  The arithmetic per row (per-lane partials in chunk order, xor-shuffle tree,
+// centred second moment) is unchanged.
+template <typename T, int MAXC, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         T* __restrict__ y, int rows, int C, float eps) {
   constexpr int EPC = sr_traits<T>::EPC;
-  constexpr int MAXC = 5;                           // chunks per lane: C <= 64*5*EPC (2560 fp16 / 1280 fp32)
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= rows) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS, lane = threadIdx.x & 63;
+  if (row0 >= rows) return;
   const int cpt = C / EPC;
-  float v[MAXC][EPC];
-  float s = 0.f;
+  float v[ROWS][MAXC][EPC];
+  float s[ROWS], q[ROWS];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int cc = lane + i * 64;
-    if (cc < cpt) {
-      load_chunk<T>(x + (int64_t)row * C + cc * EPC, v[i]);
+  for (int r = 0; r < ROWS; ++r) {
+    s[r] = 0.f;
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) s += v[i][e];
+    for (int i = 0; i < MAXC; ++i) {
+      const int cc = lane + i * 64;
+      if (cc < cpt && row0 + r < rows) load_chunk<T>(x + (int64_t)(row0 + r) * C + cc * EPC, v[r][i]);
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s / (float)C;
-  float q = 0.f;
+  for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int cc = lane + i * 64;
-    if (cc < cpt) {
+    for (int i = 0; i < MAXC; ++i) {
+      if (lane + i * 64 < cpt && row0 + r < rows) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        for (int e = 0; e < EPC; ++e) s[r] += v[r][i][e];
+      }
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = rsqrtf(q / (float)C + eps);
+  for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int cc = lane + i * 64;
-    if (cc < cpt) {
-      float o[EPC];
+    for (int r = 0; r < ROWS; ++r) s[r] += __shfl_xor(s[r], o);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[cc * EPC + e] + beta[cc * EPC + e];
-      store_chunk<T>(y + (int64_t)row * C + cc * EPC, o);
+  for (int r = 0; r < ROWS; ++r) {
+    const float mean = s[r] / (float)C;
+    s[r] = mean;
+    q[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      if (lane + i * 64 < cpt && row0 + r < rows) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { const float d = v[r][i][e] - mean; q[r] += d * d; }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) q[r] += __shfl_xor(q[r], o);
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const float mean = s[r], rstd = rsqrtf(q[r] / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int cc = lane + i * 64;
+      if (cc < cpt && row0 + r < rows) {
+        float o[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = (v[r][i][e] - mean) * rstd * gamma[cc * EPC + e] + beta[cc * EPC + e];
+        store_chunk<T>(y + (int64_t)(row0 + r) * C + cc * EPC, o);
+      }
     }
   }
 }
 
-// one wave per row: (rstd, -rstd*mean) for the LayerNorm folded into the consuming GEMM (sr_igemm_args.row_stats)
 template <typename T>
 __global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int rows, int C, float eps) {
   constexpr int EPC = sr_traits<T>::EPC;
@@ -476,9 +498,21 @@ extern "C" int sr_layernorm(const void* x, const float* gamma, const float* beta
   const int epc = dtype == SR_F16 ? 8 : 4;
   if (C % epc || C / epc > 64 * 5) SR_FAIL(SR_ERR_INVALID, "sr_layernorm: C=%d unsupported", C);
   hipStream_t st = sr_stream(stream);
-  dim3 grid(sr_cdiv(rows, 4));
-  if (dtype == SR_F16) hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)x, gamma, beta, (_Float16*)y, rows, C, eps);
-  else if (dtype == SR_F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, rows, C, eps);
+  const int cpt = C / epc;
+  auto go = [&](auto t, auto maxc, auto nrows) {
+    using T = decltype(t);
+    constexpr int MAXC = decltype(maxc)::value, ROWS = decltype(nrows)::value;
+    hipLaunchKernelGGL((layernorm_kernel<T, MAXC, ROWS>), dim3(sr_cdiv(rows, 4 * ROWS)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, eps);
+  };
+  using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+  if (dtype == SR_F16) {
+    if (cpt <= 64) go(_Float16(), I1{}, I4{}); else if (cpt <= 128) go(_Float16(), I2{}, I2{});
+    else if (cpt <= 192) go(_Float16(), I3{}, I2{}); else go(_Float16(), I5{}, I1{});
+  } else if (dtype == SR_F32) {
+    if (cpt <= 64) go(float(), I1{}, I4{}); else if (cpt <= 128) go(float(), I2{}, I2{});
+    else if (cpt <= 192) go(float(), I3{}, I2{}); else go(float(), I5{}, I1{});
+  }
   else SR_FAIL(SR_ERR_INVALID, "sr_layernorm: dtype");
   SR_CHECK_LAUNCH("sr_layernorm");
   return SR_OK;
