@@ -20,7 +20,11 @@ constexpr int KV_TILE = 64;     // keys per iteration (4 MFMA key tiles)
 // SR ("sum row"): when d is not a multiple of 16 the last V^T tile has spare rows; row d is filled with ones, so the MFMA
 // that accumulates O^T also accumulates the softmax denominator (of the SAME fp16-rounded probabilities as the numerator)
 // and the per-element v_add of the row sum disappears from the VALU-bound d=40 loop.
-template <typename T, int DQ, int DT, int QT, bool SR, int MB>
+// SHORT (Tk <= 2 tiles, the 77-token prompt): a workgroup stages the whole K / V^T ONCE into the two LDS buffers and then walks
+// several 128-query blocks (grid-stride over blockIdx.x) with no barrier inside the walk, the next block's Q fragments fetched
+// under the current block's work.  With one query block per workgroup the launch was 4096 workgroups that each paid two
+// dependent global->register->LDS round trips for 128 x 77 scores of work (53 us at B16 Tq4096 d40).
+template <typename T, int DQ, int DT, int QT, bool SR, int MB, bool SHORT = false>
 __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p) {
   constexpr int EPC = sr_traits<T>::EPC;
   constexpr int NCH = 4 * DQ;                               // 16-B chunks per K row in LDS (zero padded)
@@ -38,31 +42,37 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
   const int b = blockIdx.z, h = blockIdx.y;
   const int bk = p.Bk == 1 ? 0 : b;
   const int d = p.d;
-  const int q0 = blockIdx.x * (64 * QT) + wv * (16 * QT);
+  int q0 = blockIdx.x * (64 * QT) + wv * (16 * QT);
 
   // ---- Q fragments (B operand): lane (g,c) <- Q[q0 + qt*16 + c][h*d + s*4*EPC + g*EPC ..]
   uint4 qf[QT][DQ];
+  auto load_q = [&](uint4 (&dst)[QT][DQ], int qb0) {
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int q = q0 + qt * 16 + c16;
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q = qb0 + qt * 16 + c16;
 #pragma unroll
-    for (int s = 0; s < DQ; ++s) {
-      const int di = s * 4 * EPC + g4 * EPC;
-      if (q < p.Tq && di < d)
-        qf[qt][s] = *(const uint4*)((const T*)p.q + ((int64_t)b * p.Tq + q) * p.q_stride + h * d + di);
-      else
-        qf[qt][s] = make_uint4(0, 0, 0, 0);
+      for (int s = 0; s < DQ; ++s) {
+        const int di = s * 4 * EPC + g4 * EPC;
+        if (q < p.Tq && di < d)
+          dst[qt][s] = *(const uint4*)((const T*)p.q + ((int64_t)b * p.Tq + q) * p.q_stride + h * d + di);
+        else
+          dst[qt][s] = make_uint4(0, 0, 0, 0);
+      }
     }
-  }
+  };
+  load_q(qf, q0);
 
   f32x4 o[DT][QT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float mrow[QT], lrow[QT];
+  auto reset = [&]() {
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) { mrow[qt] = -INFINITY; lrow[qt] = 0.f; }
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { mrow[qt] = -INFINITY; lrow[qt] = 0.f; }
+  };
+  reset();
   const float sl2 = p.scale * 1.4426950408889634f;          // fold log2(e): p = exp2(s*sl2 - m)
 
   const T* kbase = (const T*)p.k + (int64_t)bk * p.Tk * p.k_stride + h * d;
@@ -109,19 +119,7 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
     }
   };
   constexpr bool DB = 2 * (K_BYTES + V_BYTES) <= 144 * 1024;   // double-buffer LDS when it fits (all fp16 shapes)
-  gload(0);
-  lstore(0);
-  if (KV_TILE < p.Tk) gload(KV_TILE);
-  int it = 0;
-  for (int k0 = 0; k0 < p.Tk; k0 += KV_TILE, ++it) {
-    __syncthreads();                                        // tile `it` visible; everyone is done with tile it-1
-    const int cur = DB ? (it & 1) : 0;
-    if constexpr (DB) {
-      if (k0 + KV_TILE < p.Tk) {
-        lstore(cur ^ 1);
-        if (k0 + 2 * KV_TILE < p.Tk) gload(k0 + 2 * KV_TILE);
-      }
-    }
+  int cur = 0, k0 = 0;
     auto tile = [&](auto tail_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
       const char* cK = sK + cur * (K_BYTES + V_BYTES);
@@ -223,18 +221,8 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
         }
       }
     };
-    if (k0 + KV_TILE > p.Tk) tile(std::true_type{}); else tile(std::false_type{});
-    if constexpr (!DB) {                                    // one LDS buffer: refill it once every wave is done reading
-      if (k0 + KV_TILE < p.Tk) {
-        __syncthreads();
-        lstore(0);
-        if (k0 + 2 * KV_TILE < p.Tk) gload(k0 + 2 * KV_TILE);
-      }
-    }
-  }
-
-  // (single-buffer variant: see the end of the loop body)
   // ---- normalise and store: lane holds O^T[d = dt*16 + 4g + r][q = qt*16 + c]
+  auto finish = [&]() {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float l = lrow[qt];
@@ -260,6 +248,57 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
         *(float4*)(orow + di) = make_float4(o[dt][qt][0] * inv, o[dt][qt][1] * inv, o[dt][qt][2] * inv, o[dt][qt][3] * inv);
       }
     }
+  }
+  };
+
+  if constexpr (SHORT) {
+    static_assert(DB, "the short-sequence walk keeps both tiles resident");
+    gload(0);
+    lstore(0);
+    if (KV_TILE < p.Tk) { gload(KV_TILE); lstore(1); }
+    __syncthreads();
+    const int qstep = gridDim.x * (64 * QT);
+    for (;;) {
+      const int qn = q0 + qstep;
+      uint4 qnext[QT][DQ];
+      const bool more = qn - wv * (16 * QT) < p.Tq;         // (wave-uniform: the block start)
+      if (more) load_q(qnext, qn);
+      cur = 0; k0 = 0;
+      if (p.Tk <= KV_TILE) tile(std::true_type{});
+      else { tile(std::false_type{}); cur = 1; k0 = KV_TILE; tile(std::true_type{}); }
+      finish();
+      if (!more) break;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int s = 0; s < DQ; ++s) qf[qt][s] = qnext[qt][s];
+      q0 = qn;
+      reset();
+    }
+  } else {
+    gload(0);
+    lstore(0);
+    if (KV_TILE < p.Tk) gload(KV_TILE);
+    int it = 0;
+    for (k0 = 0; k0 < p.Tk; k0 += KV_TILE, ++it) {
+      __syncthreads();                                      // tile `it` visible; everyone is done with tile it-1
+      cur = DB ? (it & 1) : 0;
+      if constexpr (DB) {
+        if (k0 + KV_TILE < p.Tk) {
+          lstore(cur ^ 1);
+          if (k0 + 2 * KV_TILE < p.Tk) gload(k0 + 2 * KV_TILE);
+        }
+      }
+      if (k0 + KV_TILE > p.Tk) tile(std::true_type{}); else tile(std::false_type{});
+      if constexpr (!DB) {                                  // one LDS buffer: refill it once every wave is done reading
+        if (k0 + KV_TILE < p.Tk) {
+          __syncthreads();
+          lstore(0);
+          if (k0 + 2 * KV_TILE < p.Tk) gload(k0 + 2 * KV_TILE);
+        }
+      }
+    }
+    finish();
   }
 }
 
@@ -547,6 +586,21 @@ int launch_pipe(const sr_attention_args& a, hipStream_t st) {
 }
 
 template <typename T, int DQ, int DT, int QT, bool SR = false, int MB = ((QT <= 2 && DT <= 5 && sizeof(T) == 2) ? 2 : 1)>
+int launch_short(const sr_attention_args& a, hipStream_t st) {
+  constexpr int tile_b = KV_TILE * 4 * DQ * 16 + DT * 16 * (KV_TILE * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16));
+  constexpr int lds = 2 * tile_b;
+  const int nqb = sr_cdiv(a.Tq, 64 * QT);
+  int gx = sr_cdiv(nqb, 8);                                  // ~8 query blocks per workgroup, but keep >= 2 workgroups per CU
+  while (gx < nqb && (int64_t)gx * a.heads * a.B < 512) ++gx;
+  auto k = attn_kernel<T, DQ, DT, QT, SR, MB, true>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  hipLaunchKernelGGL(k, dim3(gx, a.heads, a.B), dim3(256), lds, st, a);
+  SR_CHECK_LAUNCH("sr_attention");
+  return SR_OK;
+}
+
+template <typename T, int DQ, int DT, int QT, bool SR = false, int MB = ((QT <= 2 && DT <= 5 && sizeof(T) == 2) ? 2 : 1)>
 int launch(const sr_attention_args& a, hipStream_t st) {
   dim3 grid(sr_cdiv(a.Tq, 64 * QT), a.heads, a.B);
   constexpr int tile_b = KV_TILE * 4 * DQ * 16 + DT * 16 * (KV_TILE * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16));
@@ -575,6 +629,8 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
     // QT = 2 (32 queries per wave): everything fits in 128 VGPRs -> no AGPR<->VGPR copies around the softmax and two
     // workgroups per CU, so one wave's MFMAs overlap the other's exp/max/sum VALU work
     static const bool pipe = !(getenv("SR_ATTN_PIPE") && atoi(getenv("SR_ATTN_PIPE")) == 0);   // A-B aid
+    static const bool short_on = !(getenv("SR_ATTN_SHORT") && atoi(getenv("SR_ATTN_SHORT")) == 0);   // A-B aid
+    const bool shortk = short_on && a->Tk <= 2 * KV_TILE && a->Tq >= 512;
     if (d <= 48) {
       // long key sequences (64x64 self-attention): the software-pipelined loop, 819 vs 895 us (Bk=1) / 722 vs 815 (Bk=B) at
       // B16 T4096 d40; short ones (the 77-token prompt) stay on the simple loop, whose prologue is cheaper
@@ -587,11 +643,12 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
         if (nthr == 512) return (d & 15) ? launch_pipe<2, 3, true, 2, 512>(*a, st) : launch_pipe<2, 3, false, 2, 512>(*a, st);
         return (d & 15) ? launch_pipe<2, 3, true>(*a, st) : launch_pipe<2, 3, false>(*a, st);
       }
+      if (shortk) return (d & 15) ? launch_short<_Float16, 2, 3, 2, true>(*a, st) : launch_short<_Float16, 2, 3, 2>(*a, st);
       return (d & 15) ? launch<_Float16, 2, 3, 2, true>(*a, st) : launch<_Float16, 2, 3, 2>(*a, st);
     }
     if (d <= 64) return launch<_Float16, 2, 4, 2>(*a, st);
-    if (d <= 80) return launch<_Float16, 3, 5, 2>(*a, st);
-    if (d <= 160) return launch<_Float16, 5, 10, 2>(*a, st);
+    if (d <= 80) return shortk ? launch_short<_Float16, 3, 5, 2>(*a, st) : launch<_Float16, 3, 5, 2>(*a, st);
+    if (d <= 160) return shortk ? launch_short<_Float16, 5, 10, 2>(*a, st) : launch<_Float16, 5, 10, 2>(*a, st);
   } else if (a->dtype == SR_F32) {
     if (d <= 16) return launch<float, 1, 1, 4>(*a, st);
     if (d <= 32) return launch<float, 2, 2, 4>(*a, st);

@@ -326,6 +326,12 @@ def _attn_ref(q, k, v, heads):
     (1, 1, 80, 64, 4, 16),
     (1, 1, 80, 70, 2, 32),
     (1, 1, 64, 64, 2, 64),
+    # the resident-K/V walk over several query blocks per workgroup (fp16, Tq >= 512, Tk <= 128):
+    (2, 2, 4096, 77, 8, 40),      # 64x64-level prompt attention: 32 query blocks, 8 per workgroup
+    (3, 3, 1000, 77, 4, 40),      # ragged Tq: the last block is partial, the last walk shorter
+    (2, 1, 640, 128, 4, 80),      # two full key tiles, shared K/V, d = 80
+    (2, 2, 1024, 64, 2, 48),      # a single key tile, d a multiple of 16 (no ones row)
+    (1, 1, 512, 100, 2, 160),     # d = 160
 ])
 def test_attention(ops, dtype, cfg):
     B, Bk, Tq, Tk, heads, d = cfg
