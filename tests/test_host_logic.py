@@ -111,3 +111,52 @@ def test_gbuffer_dump_layout_matches_reference(tmp_path):
     for name in ("id", "pos", "noise"):
         got = np.load(tmp_path / name / f"{name}_{f}.npy")
         assert got.dtype == g[name + "_npy"].dtype and (got == g[name + "_npy"]).all(), name
+
+
+def test_call_order_tickets_serialize_sections_in_call_order():
+    """pipeline.CallOrder: calls in flight on several threads take their RNG-draw and corr-map-update sections in call order,
+    and a failure inside a section releases the waiters instead of deadlocking them"""
+    import threading
+    import time
+    from stable_renderer_amd.pipeline import CallOrder
+    order, log = CallOrder(), []
+
+    def work(i, k):
+        for c in range(i, 9, k):
+            with order.turn("rng", c):
+                log.append(("rng", c))
+                time.sleep(0.002 * ((c * 7) % 3))
+            time.sleep(0.001 * ((c * 5) % 4))            # "sampling": runs concurrently with the other threads
+            with order.turn("bake", c):
+                log.append(("bake", c))
+    ts = [threading.Thread(target=work, args=(i, 3)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=30)
+        assert not t.is_alive()
+    assert [c for k, c in log if k == "rng"] == list(range(9))
+    assert [c for k, c in log if k == "bake"] == list(range(9))
+    assert all(log.index(("rng", c)) < log.index(("bake", c)) for c in range(9))
+
+    order2, seen = CallOrder(), []
+
+    def boom():
+        try:
+            with order2.turn("rng", 0):
+                raise RuntimeError("x")
+        except RuntimeError:
+            seen.append("raised")
+
+    def waiter():
+        try:
+            with order2.turn("rng", 1):
+                seen.append("entered")
+        except RuntimeError as e:
+            seen.append(str(e))
+    tw = threading.Thread(target=waiter)
+    tw.start()
+    time.sleep(0.05)
+    boom()
+    tw.join(timeout=10)
+    assert not tw.is_alive() and seen == ["raised", "another in-flight call failed"]
