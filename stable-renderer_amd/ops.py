@@ -156,6 +156,18 @@ def tune_igemm(ar, min_flops=1.0e9, reps=4, allow_split=True):
                 e1.synchronize()
                 t = e0.elapsed_time(e1) / n
                 times[(tile, split)] = min(t, times.get((tile, split), t)) if rnd == 1 else t
+        # play-off: the three fastest are timed once more with a longer run (the table has 14 entries now, so a single noisy
+        # sample is more likely to crown the wrong one); a candidate keeps the minimum of its samples
+        for tile, split in sorted(times, key=times.get)[:3]:
+            ar.tile, ar.split = tile, split
+            n = max(2 * reps, min(80, int(2.0 / max(times[(tile, split)], 1e-3))))      # ~2 ms
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                lib.sr_igemm(C.byref(ar), st)
+            e1.record()
+            e1.synchronize()
+            times[(tile, split)] = min(times[(tile, split)], e0.elapsed_time(e1) / n)
         best, best_t = (0, 0 if allow_split else -1), None
         for c in _CANDIDATES:                                # 3 % hysteresis towards the earlier (heuristic-first) entry
             if c in times and (best_t is None or times[c] < best_t * 0.97):
