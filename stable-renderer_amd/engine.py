@@ -190,7 +190,11 @@ class Engine:
     _instance: Optional["Engine"] = None
 
     def __init__(self, winSize=(512, 512), mode=EngineMode.GAME, baking_interval=8, target_device=0, pipeline=None,
-                 max_frames=None, **ignored):
+                 max_frames=None, diffuse_workflow=None, disableComfyUI=False, **ignored):
+        """diffuse_workflow: a ``workflow.Workflow`` or the path of a workflow JSON (engine.py:97, diffusionManager.py:36-77): the
+        graph every submitted EngineData runs through (``workflow.PromptExecutor``, kept across frames so loaders are cached);
+        ``disableComfyUI=True`` rasterises only, as in the reference.  ``pipeline`` (a callable EngineData -> images) takes
+        precedence when given."""
         Engine._instance = self
         GameObject._all = []
         self.mode, self.baking_interval = mode, baking_interval
@@ -202,6 +206,21 @@ class Engine:
         self.RenderManager.GlobalBGNoise = torch.randn(1, H, W, 4, dtype=torch.float32).to(self.device)   # renderManager.py:869-875
         self.gbuf = S.GBuffer(W, H, device=self.device)
         self.pipeline = pipeline                          # callable(EngineData) -> images (N,H,W,3) or None (raster only)
+        self.DiffusionManager = _Managers()
+        self.DiffusionManager.Workflow, self.DiffusionManager.Executor = None, None
+        if pipeline is None and diffuse_workflow is not None and not disableComfyUI:
+            from . import workflow as WF
+            wf = diffuse_workflow if isinstance(diffuse_workflow, WF.Workflow) else WF.Workflow.Load(diffuse_workflow)
+            ex = WF.PromptExecutor()
+            self.DiffusionManager.Workflow, self.DiffusionManager.Executor = wf, ex
+
+            def _submit(engine_data):
+                ctx = WF.run_workflow(wf, engine_data=engine_data, executor=ex)
+                if not ctx.success or ctx.final_output is None:          # renderManager.py:1014-1015
+                    mes = ctx.status_messages[-1][1] if ctx.status_messages else {}
+                    raise ValueError(f"Prompt execution failed: {mes.get('exception_type')}: {mes.get('exception_message')}")
+                return ctx.final_output.frame_color
+            self.pipeline = _submit
         self.max_frames = max_frames
         self._exit = False
         self._acc = {}
@@ -268,7 +287,17 @@ class Engine:
                 for m in r.materials:
                     corr[(sp.spriteID if sp else 0, m.materialID)] = r.corrmap
         noise = cat("noise_maps")
-        return EngineData(frame_indices=list(range(len(a["frame_indices"]))), color_maps=cat("color_maps"),
+        # sprites and environment prompts submitted by the components (renderManager.py:678-703, ai/sprite.py:44, camera bgPrompt)
+        from .types import EnvPrompt, Sprite, SpriteInfos
+        sprites = SpriteInfos()
+        for o in GameObject._all:
+            sp = o.getComponent(SpriteInfo)
+            if sp is not None:
+                sprites[sp.spriteID] = Sprite(sp.spriteID, prompt=sp.prompt or "")
+        cams = [c for o in GameObject._all for c in o.components if isinstance(c, Camera)]
+        bg = cams[0].bgPrompt if cams else None
+        envs = [EnvPrompt(prompt=bg or "") for _ in a["frame_indices"]]
+        return EngineData(sprite_infos=sprites, env_prompts=envs, frame_indices=list(range(len(a["frame_indices"]))), color_maps=cat("color_maps"),
                           id_maps=IDMap(cat("id_maps").contiguous()), pos_maps=cat("pos_maps"), normal_maps=cat("normal_maps"),
                           depth_maps=cat("depth_maps"), canny_maps=cat("canny_maps"), masks=cat("masks"),
                           noise_maps=LATENT(samples=torch.zeros_like(noise), noise=noise), correspond_maps=corr)

@@ -89,3 +89,61 @@ def test_sequence_loaders_read_a_dump(tmp_path):
     assert abs(float(img[1, 5, 5, 0]) - int(0.5 * 255) / 255.0) < 1e-6
     with pytest.raises(FileNotFoundError):
         N.NoiseSequenceLoader()(str(tmp_path / "nope"))
+
+
+def test_engine_runs_a_shipped_workflow_graph(monkeypatch):
+    """Engine.Run(diffuse_workflow=<shipped JSON>) — the reference's script API (engine.py:97, diffusionManager.py:36-77):
+    every submitted EngineData goes through workflow.PromptExecutor; sprites / camera bgPrompt reach SceneTextEncode; the
+    DefaultCorresponder VAE callback bakes the corr-map; loaders run once for the whole session."""
+    from stable_renderer_amd import synth, weights as WT
+    from stable_renderer_amd.corrmap import CorrespondMap
+    from stable_renderer_amd.engine import (Camera, CorrMapRenderer, DefaultTextureType, Engine, EngineMode, GameObject, Material,
+                                            SpriteInfo, Texture)
+    from stable_renderer_amd.graph_nodes import SyntheticCLIP
+    from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes
+    from stable_renderer_amd.scene import Mesh
+    from stable_renderer_amd.unet import SD15_CFG
+    monkeypatch.setenv("SR_DTYPE", "fp32")
+    monkeypatch.setenv("SR_AUTOTUNE", "0")
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    ns, norms = unet_names_shapes(cfg)
+    vns, vnorms = vae_decoder_names_shapes(ch=32)
+    WT.clear_registry()
+    WT.register_checkpoint("dreamshaper_8.safetensors", lambda: dict(
+        unet=synth.synth_state_dict(ns, seed=1, norm_names=norms), vae=synth.synth_state_dict(vns, seed=3, norm_names=vnorms),
+        clip=SyntheticCLIP(ctx_dim=64), unet_cfg=cfg))
+    WT.register_lora("lcm/SD1.5/pytorch_lora_weights.safetensors", lambda: {})          # an empty LoRA: nothing to merge
+    seen = []
+
+    class Sample(Engine):
+        def beforePrepare(self):
+            cam = GameObject('Camera', position=[0, 1.0, 0.6])
+            cam.addComponent(Camera, bgPrompt='misty forest')
+            cam.transform.lookAt([0, 0, 0])
+            w, h = self.WindowManager.WindowSize
+            self.corrmap = CorrespondMap(k=3, width=w, height=h)
+            mat = Material.DefaultTransparentMaterial()
+            mat.addDefaultTexture(Texture.CreateNoiseTex(w, h, seed=3), DefaultTextureType.NoiseTex)
+            floor = GameObject('floor', position=[0, 0, 0], scale=20.0)              # fills the frame: every pixel carries an id
+            floor.addComponent(SpriteInfo, auto_spriteID=True, prompt='mossy stone floor')
+            floor.addComponent(CorrMapRenderer, corrmaps=self.corrmap, materials=[mat], use_texcoord_id=True, mesh=Mesh.Plane(4))
+
+        def beforeFrameEnd(self):
+            seen.append(len(self.outputs))
+
+    e = Sample.Run(winSize=(128, 128), mode=EngineMode.BAKE, baking_interval=2, max_frames=5,
+                   diffuse_workflow=os.path.join(ROOT, "tests", "golden", "workflows", "no-control-bake.json"))
+    torch.cuda.synchronize()
+    assert len(e.outputs) == 2 and seen == [0, 0, 1, 1, 2]                            # submits after frames 2 and 4
+    assert tuple(e.outputs[0].shape) == (3, 128, 128, 3) and tuple(e.outputs[1].shape) == (2, 128, 128, 3)
+    assert all(bool(torch.isfinite(o).all()) and float(o.min()) >= 0 and float(o.max()) <= 1 for o in e.outputs)
+    assert int(e.corrmap.writtens.sum()) > 0
+    ex = e.DiffusionManager.Executor
+    ctx = ex.latest_context
+    assert ctx.success and not ({"4", "11"} & ctx.executed_node_ids)                  # checkpoint + LoRA cached from the first call
+    assert ctx.engine_data.env_prompts[0].prompt == 'misty forest'
+    assert [s.prompt for s in ctx.engine_data.sprite_infos.values()] == ['mossy stone floor']
+    WT.clear_registry()
+    with pytest.raises(ValueError, match="Prompt execution failed"):                 # renderManager.py:1014-1015
+        Sample.Run(winSize=(128, 128), mode=EngineMode.BAKE, baking_interval=2, max_frames=3,
+                   diffuse_workflow=os.path.join(ROOT, "tests", "golden", "workflows", "no-control-bake.json"))
