@@ -381,6 +381,30 @@ def sec_unet():
         save("unet_sd15_16", x=x, t=t, ctx=ctx, y=y)
 
 
+# SDXL-family topology (comfy/supported_models.py:153-160) at 1/5 width: no attention at level 0, deeper transformers below,
+# fixed head width, linear proj_in / proj_out, vector conditioning through label_emb
+SDXL_TINY = {'use_checkpoint': False, 'image_size': 32, 'out_channels': 4, 'use_spatial_transformer': True, 'legacy': False,
+             'num_classes': 'sequential', 'adm_in_channels': 192, 'dtype': torch.float32, 'in_channels': 4, 'model_channels': 64,
+             'num_res_blocks': [2, 2, 2], 'transformer_depth': [0, 0, 2, 2, 3, 3], 'channel_mult': [1, 2, 4],
+             'transformer_depth_middle': 3, 'use_linear_in_transformer': True, 'context_dim': 128, 'num_head_channels': 32,
+             'num_heads': -1, 'transformer_depth_output': [0, 0, 0, 2, 2, 2, 3, 3, 3],
+             'use_temporal_attention': False, 'use_temporal_resblock': False}
+
+
+def sec_sdxl():
+    import comfy.ldm.modules.attention as att
+    att.optimized_attention = att.attention_basic
+    with torch.no_grad():
+        m, ns, norm = build_unet(SDXL_TINY, seed=4)
+        _jdump({"names_shapes": ns, "norm_names": norm}, os.path.join(GOLD, "unet_sdxl_tiny_keys.json"))
+        x = rnd(5, 2, 4, 16, 16)
+        t = torch.tensor([731.0, 731.0])
+        ctx = rnd(6, 2, 77, 128)
+        yv = rnd(7, 2, 192)
+        y = m(x, t, context=ctx, y=yv, transformer_options={})
+        save("unet_sdxl_tiny", x=x, t=t, ctx=ctx, yvec=yv, y=y)
+
+
 def sec_vae():
     from comfy.ldm.modules.diffusionmodules.model import Decoder
     import comfy.ldm.modules.diffusionmodules.model as mm
@@ -728,7 +752,7 @@ def sec_workflow():
 
 SECTIONS = dict(math=sec_math, idmap=sec_idmap, overlap=sec_overlap, corrmap=sec_corrmap, noisepool=sec_noisepool,
                 sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet, legacy=sec_legacy,
-                gbufdump=sec_gbufdump, workflow=sec_workflow)
+                gbufdump=sec_gbufdump, workflow=sec_workflow, sdxl=sec_sdxl)
 
 if __name__ == "__main__":
     todo = _ARGV or list(SECTIONS)

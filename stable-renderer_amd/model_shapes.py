@@ -14,9 +14,10 @@ def _res(p, cin, cout, emb, out):
     return [f"{p}.in_layers.0.weight", f"{p}.out_layers.0.weight"]
 
 
-def _st(p, c, ctx, depth, out):
+def _st(p, c, ctx, depth, out, linear=False):
     norms = [f"{p}.norm.weight"]
-    out += [(f"{p}.norm.weight", (c,)), (f"{p}.norm.bias", (c,)), (f"{p}.proj_in.weight", (c, c, 1, 1)), (f"{p}.proj_in.bias", (c,))]
+    pshape = (c, c) if linear else (c, c, 1, 1)        # use_linear_in_transformer (SDXL): nn.Linear instead of a 1x1 conv
+    out += [(f"{p}.norm.weight", (c,)), (f"{p}.norm.bias", (c,)), (f"{p}.proj_in.weight", pshape), (f"{p}.proj_in.bias", (c,))]
     for i in range(depth):
         b = f"{p}.transformer_blocks.{i}"
         out += [(f"{b}.attn1.to_q.weight", (c, c)), (f"{b}.attn1.to_k.weight", (c, c)), (f"{b}.attn1.to_v.weight", (c, c)),
@@ -28,7 +29,7 @@ def _st(p, c, ctx, depth, out):
                 (f"{b}.norm2.weight", (c,)), (f"{b}.norm2.bias", (c,)), (f"{b}.norm1.weight", (c,)), (f"{b}.norm1.bias", (c,)),
                 (f"{b}.norm3.weight", (c,)), (f"{b}.norm3.bias", (c,))]
         norms += [f"{b}.norm2.weight", f"{b}.norm1.weight", f"{b}.norm3.weight"]
-    out += [(f"{p}.proj_out.weight", (c, c, 1, 1)), (f"{p}.proj_out.bias", (c,))]
+    out += [(f"{p}.proj_out.weight", pshape), (f"{p}.proj_out.bias", (c,))]
     return norms
 
 
@@ -36,6 +37,11 @@ def unet_names_shapes(cfg):
     mc, emb, ctx = cfg["model_channels"], 4 * cfg["model_channels"], cfg["context_dim"]
     out, norms = [], []
     out += [("time_embed.0.weight", (emb, mc)), ("time_embed.0.bias", (emb,)), ("time_embed.2.weight", (emb, emb)), ("time_embed.2.bias", (emb,))]
+    lin = bool(cfg.get("use_linear_in_transformer"))
+    if cfg.get("adm_in_channels"):                      # num_classes="sequential" (SDXL): label_emb = [Linear, SiLU, Linear]
+        adm = cfg["adm_in_channels"]
+        out += [("label_emb.0.0.weight", (emb, adm)), ("label_emb.0.0.bias", (emb,)), ("label_emb.0.2.weight", (emb, emb)),
+                ("label_emb.0.2.bias", (emb,))]
     out += [("input_blocks.0.0.weight", (mc, cfg["in_channels"], 3, 3)), ("input_blocks.0.0.bias", (mc,))]
     chans = [mc]
     ch, bi = mc, 1
@@ -48,7 +54,7 @@ def unet_names_shapes(cfg):
             ch = cout
             d = td.pop(0)
             if d > 0:
-                norms += _st(f"input_blocks.{bi}.1", ch, ctx, d, out)
+                norms += _st(f"input_blocks.{bi}.1", ch, ctx, d, out, lin)
             chans.append(ch)
             bi += 1
         if lev != nlev - 1:
@@ -56,7 +62,7 @@ def unet_names_shapes(cfg):
             chans.append(ch)
             bi += 1
     norms += _res("middle_block.0", ch, ch, emb, out)
-    norms += _st("middle_block.1", ch, ctx, cfg["transformer_depth_middle"], out)
+    norms += _st("middle_block.1", ch, ctx, cfg["transformer_depth_middle"], out, lin)
     norms += _res("middle_block.2", ch, ch, emb, out)
     tdo = list(cfg["transformer_depth_output"])
     bo = 0
@@ -69,7 +75,7 @@ def unet_names_shapes(cfg):
             d = tdo.pop()
             j = 1
             if d > 0:
-                norms += _st(f"output_blocks.{bo}.1", ch, ctx, d, out)
+                norms += _st(f"output_blocks.{bo}.1", ch, ctx, d, out, lin)
                 j = 2
             if lev > 0 and i == cfg["num_res_blocks"][lev]:
                 out += [(f"output_blocks.{bo}.{j}.conv.weight", (ch, ch, 3, 3)), (f"output_blocks.{bo}.{j}.conv.bias", (ch,))]

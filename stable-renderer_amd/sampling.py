@@ -189,6 +189,11 @@ class DiffusionRunner:
         self._hints = list(hints)
         self._hints_loaded = False
 
+    def set_vector_conditioning(self, y_positive, y_negative=None):
+        """SDXL-family ``y`` (pooled text + size / crop embeddings, (1 | N, adm_in_channels)); the negative half defaults to the
+        positive one (comfy/model_base.py SDXL.encode_adm builds both from their own pooled outputs)"""
+        self._y = (y_positive, y_positive if y_negative is None else y_negative)
+
     def set_conditioning(self, positive, negative):
         """positive / negative: (1 | N, n_ctx, ctx_dim) text embeddings (CONDRegular.process_cond repeats a single
         embedding to the batch, comfy/conds.py:23-26).  Batch order = [uncond frames..., cond frames...]."""
@@ -204,6 +209,16 @@ class DiffusionRunner:
             p["ctx"][N:].copy_(pos)
         else:
             p["ctx"].copy_(pos)
+        if p.get("y") is not None:
+            if getattr(self, "_y", None) is None:
+                raise ValueError("this UNet takes vector conditioning (adm_in_channels): call set_vector_conditioning() before sampling")
+            yb, adm = p["y"], self.unet.cfg["adm_in_channels"]
+            yp, yn = (t.to(yb.device).to(yb.dtype).expand(N, -1) for t in self._y)
+            if self.copies == 2:
+                yb[:N, :adm].copy_(yn)
+                yb[N:, :adm].copy_(yp)
+            else:
+                yb[:, :adm].copy_(yp)
         p["prologue"].run()
         if p.get("cn") is not None:
             if self._hints is None:

@@ -25,6 +25,14 @@ SD15_CFG = dict(in_channels=4, out_channels=4, model_channels=320, num_res_block
                 transformer_depth_output=[1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0], context_dim=768, num_heads=8)
 
 
+# comfy/supported_models.py:153-160 (SDXL base): no attention at the first level, 2 / 10 transformer blocks below, 64-wide heads,
+# linear proj_in / proj_out, 2816-wide vector conditioning through label_emb, 2048-wide context
+SDXL_CFG = dict(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=[2, 2, 2], channel_mult=[1, 2, 4],
+                transformer_depth=[0, 0, 2, 2, 10, 10], transformer_depth_middle=10,
+                transformer_depth_output=[0, 0, 0, 2, 2, 2, 10, 10, 10], context_dim=2048, num_heads=-1, num_head_channels=64,
+                use_linear_in_transformer=True, adm_in_channels=2816)
+
+
 def _cdiv(a, b):
     return (a + b - 1) // b
 
@@ -143,6 +151,9 @@ class BlockLowering:
     def tblock(self, p, hcur, Cc, HW):
         pb, pro, W, B, cfg = self.pb, self.pro, self.W, self.B, self.cfg
         mc, heads, emb_s, ctx, n_ctx, ldt_ctx = cfg["model_channels"], cfg["num_heads"], self.emb_s, self.ctx, self.n_ctx, self.ldt_ctx
+        nhc = cfg.get("num_head_channels") or -1
+        if nhc > 0:                                    # SDXL family: fixed head width, head count per level (openaimodel.py:601-608)
+            heads = Cc // nhc
         inject_idx, sel = self.inject_idx, self.sel
         d = Cc // heads
         fold = self.fold_ln and (inject_idx is None or (HW * 8) % 16 == 0)     # (the statistics rows are gathered in 16-byte units)
@@ -288,6 +299,20 @@ class UNet:
         pb.igemm(temb, W["time_embed.0"], e1, B, 1, 1, mc, 4 * mc, bias=W["time_embed.0.b"], act=1)
         e2 = pb.buf(B, 4 * mc)
         pb.igemm(e1, W["time_embed.2"], e2, B, 1, 1, 4 * mc, 4 * mc, bias=W["time_embed.2.b"])
+        y_in = None
+        if cfg.get("adm_in_channels"):
+            # vector conditioning (SDXL: pooled text + size / crop embeddings): emb = time_embed(t) + label_emb(y)
+            # (openaimodel.py:862-864).  y is constant over a sampling run -> label_emb runs in the prologue plan.
+            adm = cfg["adm_in_channels"]
+            adm_pad = _cdiv(adm, self.ke) * self.ke
+            y_in = pro.buf(B, adm_pad, zero=True)
+            l1 = pro.buf(B, 4 * mc)
+            pro.igemm(y_in, W["label_emb.0.0"], l1, B, 1, 1, adm_pad, 4 * mc, bias=W["label_emb.0.0.b"], act=1)
+            lab = pro.buf(B, 4 * mc)
+            pro.igemm(l1, W["label_emb.0.2"], lab, B, 1, 1, 4 * mc, 4 * mc, bias=W["label_emb.0.2.b"])
+            e3 = pb.buf(B, 4 * mc)
+            pb.add(e2, lab, e3)
+            e2 = e3
         emb_s = pb.buf(B, 4 * mc)
         pb.silu(e2, emb_s)                             # every ResBlock applies SiLU first (emb_layers.0)
 
@@ -369,5 +394,5 @@ class UNet:
         pb.nhwc_to_nchw(o_nhwc, out, B, oc, hh * ww, oc)
         flops = pb.flops
         step = pb.take()
-        return dict(prologue=pro.take(), step=step, x=x_in, t=t_in, ctx=ctx, out=out, flops=flops, inject=sel,
+        return dict(prologue=pro.take(), step=step, x=x_in, t=t_in, ctx=ctx, y=y_in, out=out, flops=flops, inject=sel,
                     segments=low.segments + [step], points=low.points)

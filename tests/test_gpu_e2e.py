@@ -260,3 +260,28 @@ def test_calls_in_flight_equal_the_sequential_loop(monkeypatch):
     assert torch.equal(r1, r2)                                  # the global generator ends in the same state
     v3, w3, r3 = bake(3)
     assert torch.equal(w1, w3) and same(v1, v3) and torch.equal(r1, r3)
+
+
+def test_sampling_with_an_sdxl_family_unet_needs_and_uses_vector_conditioning():
+    """DiffusionRunner over the SDXL-family lowering (label_emb): y is required, reaches both CFG halves, changes the result"""
+    from stable_renderer_amd import synth
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    from stable_renderer_amd.sampling import DiffusionRunner
+    from stable_renderer_amd.unet import UNet
+    cfg = dict(in_channels=4, out_channels=4, model_channels=64, num_res_blocks=[2, 2, 2], channel_mult=[1, 2, 4],
+               transformer_depth=[0, 0, 1, 1, 2, 2], transformer_depth_middle=2, transformer_depth_output=[0, 0, 0, 1, 1, 1, 2, 2, 2],
+               context_dim=128, num_heads=-1, num_head_channels=32, use_linear_in_transformer=True, adm_in_channels=192)
+    ns, norms = unet_names_shapes(cfg)
+    net = UNet(synth.synth_state_dict(ns, seed=6, norm_names=norms), cfg, dtype=torch.float32)
+    g = torch.Generator().manual_seed(2)
+    noise, pos, neg = torch.randn(2, 4, 16, 16, generator=g), torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    r = DiffusionRunner(net, 2, 16, 16, 5.0, use_graph=False)
+    r.set_conditioning(pos, neg)
+    with pytest.raises(ValueError, match="vector conditioning"):
+        r.sample(noise, 2, "euler", "normal", seed=1)
+    outs = []
+    for s in (0, 0, 1):
+        r.set_vector_conditioning(torch.randn(1, 192, generator=torch.Generator().manual_seed(s)))
+        out, _ = r.sample(noise, 2, "euler", "normal", seed=1)
+        outs.append(out.clone())
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])

@@ -23,7 +23,7 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def run_unet(sd, cfg, dtype, x, t, ctx, inject=None):
+def run_unet(sd, cfg, dtype, x, t, ctx, inject=None, yvec=None):
     from stable_renderer_amd.unet import UNet
     net = UNet(sd, cfg, dtype=dtype)
     B = x.shape[0]
@@ -31,6 +31,8 @@ def run_unet(sd, cfg, dtype, x, t, ctx, inject=None):
     p["x"].copy_(x)
     p["t"].copy_(t)
     p["ctx"].copy_(ctx.to(dtype))
+    if yvec is not None:
+        p["y"][:, :yvec.shape[1]].copy_(yvec.to(dtype))
     p["prologue"].run()
     p["step"].run()
     torch.cuda.synchronize()
@@ -67,6 +69,28 @@ def test_unet_sd15_shapes(dtype, atol):
         p["step"].launch()
     s.synchronize()
     assert torch.equal(p["out"].cpu(), y)
+
+
+SDXL_TINY = dict(in_channels=4, out_channels=4, model_channels=64, num_res_blocks=[2, 2, 2], channel_mult=[1, 2, 4],
+                 transformer_depth=[0, 0, 2, 2, 3, 3], transformer_depth_middle=3, transformer_depth_output=[0, 0, 0, 2, 2, 2, 3, 3, 3],
+                 context_dim=128, num_heads=-1, num_head_channels=32, use_linear_in_transformer=True, adm_in_channels=192)
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
+def test_unet_sdxl_family(dtype, atol):
+    """SDXL topology (BASELINE config 5; comfy/supported_models.py:153-160) at 1/5 width against the reference UNetModel: no
+    attention at the first level, 2 / 3 transformer blocks per SpatialTransformer below, 32-wide heads (2 / 4 / 8 per level),
+    linear proj_in / proj_out, vector conditioning through label_emb"""
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    from stable_renderer_amd.unet import SDXL_CFG
+    d = np.load(os.path.join(GOLD, "unet_sdxl_tiny.npz"))
+    sd = _sd("unet_sdxl_tiny_keys.json", 4)
+    y, p = run_unet(sd, SDXL_TINY, dtype, T(d["x"]), T(d["t"]), T(d["ctx"]), yvec=T(d["yvec"]))
+    ref = T(d["y"])
+    err = (y - ref).abs().max().item()
+    assert err < atol * max(1.0, ref.abs().max().item()), err
+    ns, _ = unet_names_shapes(SDXL_CFG)                                # the full-size table is the 2.57 B-parameter SDXL base UNet
+    assert sum(int(np.prod(s)) for _, s in ns) == 2567463684
 
 
 @pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
