@@ -403,6 +403,15 @@ def sec_sdxl():
         yv = rnd(7, 2, 192)
         y = m(x, t, context=ctx, y=yv, transformer_options={})
         save("unet_sdxl_tiny", x=x, t=t, ctx=ctx, yvec=yv, y=y)
+        # SDXL.encode_adm itself (comfy/model_base.py:352-369) on a stub that only carries the 256-wide Timestep embedder
+        import types
+        import comfy.model_base as mb
+        from comfy.ldm.modules.diffusionmodules.openaimodel import Timestep
+        stub = types.SimpleNamespace(embedder=Timestep(256), noise_augmentor=None)
+        pooled = rnd(8, 2, 1280)
+        a1 = mb.SDXL.encode_adm(stub, pooled_output=pooled, width=1024, height=1024)
+        a2 = mb.SDXL.encode_adm(stub, pooled_output=pooled, width=832, height=1216, crop_w=8, crop_h=16, target_width=1024, target_height=1024)
+        save("sdxl_adm", pooled=pooled, adm_default=a1, adm_custom=a2)
 
 
 def sec_vae():

@@ -22,8 +22,8 @@ class SyntheticCLIP:
     across frames by the executor — it is off the hot path, and no text-encoder weights exist offline; a
     checkpoint provider may hand over any object with this surface instead (e.g. a transformers CLIPTextModel wrapper)."""
 
-    def __init__(self, ctx_dim=768, n_ctx=77, seed=0):
-        self.ctx_dim, self.n_ctx, self.seed = ctx_dim, n_ctx, seed
+    def __init__(self, ctx_dim=768, n_ctx=77, seed=0, pooled_dim=None):
+        self.ctx_dim, self.n_ctx, self.seed, self.pooled_dim = ctx_dim, n_ctx, seed, pooled_dim
 
     def tokenize(self, text):
         return str(text)
@@ -31,7 +31,8 @@ class SyntheticCLIP:
     def encode_from_tokens(self, tokens, return_pooled=False):
         g = torch.Generator().manual_seed((zlib.crc32(tokens.encode("utf-8")) + 7919 * self.seed) & 0x7FFFFFFF)
         cond = torch.randn(1, self.n_ctx, self.ctx_dim, generator=g)
-        return (cond, cond[:, -1].clone()) if return_pooled else cond
+        pooled = cond[:, -1].clone() if self.pooled_dim is None else torch.randn(1, self.pooled_dim, generator=g)
+        return (cond, pooled) if return_pooled else cond
 
 
 class _NoCLIP:
@@ -128,8 +129,9 @@ class CheckpointLoaderSimple:
             unet_sd, vae_sd, clip = r["unet"], r.get("vae"), r.get("clip")
             vae = VAEDecoder(vae_sd, dtype=dt) if (output_vae and vae_sd is not None) else None
         else:                                                    # a full SD1.x checkpoint file
-            cfg = dict(SD15_CFG)
             unet_sd, vae_sd, _ = WT.split_checkpoint(r)
+            from .unet import SDXL_CFG
+            cfg = dict(SDXL_CFG if "label_emb.0.0.weight" in unet_sd else SD15_CFG)   # (model_detection.py: SDXL carries label_emb)
             clip = None
             vae = VAEDecoder(vae_sd, dtype=dt, prefix="decoder.") if output_vae else None
         if clip is None:

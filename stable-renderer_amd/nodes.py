@@ -39,6 +39,13 @@ class MODEL:
         return self._runners[key]
 
 
+def pooled_of(c):
+    """the 'pooled_output' a CLIPTextEncode-style node left in the conditioning, or None"""
+    if isinstance(c, torch.Tensor) or not c:
+        return None
+    return c[0][1].get("pooled_output")
+
+
 def unwrap_conditioning(c):
     """CONDITIONING ([[cond, {..., 'control': AppliedControl}], ...], comfyUI/nodes.py:53-65, 806-848) or a bare
     (1|N, 77, ctx) tensor -> (tensor, [AppliedControl, ...] newest first)"""
@@ -244,6 +251,7 @@ def custom_ksampler(model: MODEL, seed, steps, cfg, sampler_name, scheduler, pos
     applied to the positive conditioning serve both halves of the batch (control_apply_to_uncond, samplers.py:520-548).
     ``engine_data`` / ``corresponder`` reach the attention blocks through the plan (K/V injection)."""
     latent_image = latent["samples"]
+    pooled = (pooled_of(positive), pooled_of(negative))
     positive, controls = unwrap_conditioning(positive)
     negative, _ = unwrap_conditioning(negative)
     N, _, h, w = latent_image.shape
@@ -270,6 +278,15 @@ def custom_ksampler(model: MODEL, seed, steps, cfg, sampler_name, scheduler, pos
         nets.append(net)
     run = model.runner(N, h, w, cfg, controlnets=nets)
     run.set_conditioning(positive, negative)
+    adm = model.cfg.get("adm_in_channels")
+    if adm:                                            # SDXL family: y from the pooled text embedding + size embeddings
+        from .sampling import encode_adm_sdxl
+        if pooled[0] is None:
+            raise ValueError("this model takes vector conditioning: the positive conditioning carries no 'pooled_output'")
+        ys = [encode_adm_sdxl(pl if pl is not None else pooled[0], width=w * 8, height=h * 8) for pl in pooled]
+        if ys[0].shape[1] != adm:
+            raise ValueError(f"pooled_output width {ys[0].shape[1] - 1536} does not match adm_in_channels {adm} - 1536")
+        run.set_vector_conditioning(ys[0], ys[1])
     if controls:
         run.set_control_hints([c.hint for c in controls])
     n_rand = None

@@ -70,6 +70,21 @@ def calculate_sigmas_scheduler(ms, scheduler_name, steps):
     raise ValueError("error invalid scheduler " + str(scheduler_name))
 
 
+def encode_adm_sdxl(pooled_output, width, height, crop_w=0, crop_h=0, target_width=None, target_height=None):
+    """SDXL.encode_adm (comfy/model_base.py:352-369): y = [pooled text embedding | 256-wide sinusoidal embeddings of height,
+    width, crop_h, crop_w, target_height, target_width]  -> (n, pooled + 1536)"""
+    target_width = width if target_width is None else target_width
+    target_height = height if target_height is None else target_height
+    half = 128
+    freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+    out = []
+    for v in (height, width, crop_h, crop_w, target_height, target_width):
+        args = torch.Tensor([v])[:, None].float() * freqs[None]
+        out.append(torch.cat([torch.cos(args), torch.sin(args)], dim=-1))
+    flat = torch.flatten(torch.cat(out)).unsqueeze(dim=0).repeat(pooled_output.shape[0], 1)
+    return torch.cat((pooled_output.to(flat.device).float(), flat), dim=1)
+
+
 class SamplingCallbackContext:
     """comfyUI/types/runtime.py:543-593 (fields a corresponder reads)."""
 

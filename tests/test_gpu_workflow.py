@@ -147,3 +147,31 @@ def test_missing_weights_fail_loudly(monkeypatch):
     assert not ctx.success and ctx.final_output is None
     ev, mes = ctx.status_messages[-1]
     assert ev == "execution_error" and mes["node_type"] == "CheckpointLoaderSimple" and "FileNotFoundError" in mes["exception_type"]
+
+
+def test_sdxl_family_checkpoint_through_the_nodes(monkeypatch):
+    """an SDXL-topology checkpoint provider: KSampler builds y = [pooled | size embeddings] (SDXL.encode_adm) from the
+    conditioning's pooled_output; a conditioning without it is refused"""
+    from stable_renderer_amd import graph_nodes as G, synth, weights as WT
+    from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes
+    from stable_renderer_amd.types import LATENT
+    monkeypatch.setenv("SR_DTYPE", "fp32")
+    monkeypatch.setenv("SR_AUTOTUNE", "0")
+    cfg = dict(in_channels=4, out_channels=4, model_channels=64, num_res_blocks=[2, 2, 2], channel_mult=[1, 2, 4],
+               transformer_depth=[0, 0, 1, 1, 2, 2], transformer_depth_middle=2, transformer_depth_output=[0, 0, 0, 1, 1, 1, 2, 2, 2],
+               context_dim=128, num_heads=-1, num_head_channels=32, use_linear_in_transformer=True, adm_in_channels=1536 + 64)
+    ns, norms = unet_names_shapes(cfg)
+    vns, vnorms = vae_decoder_names_shapes(ch=32)
+    WT.clear_registry()
+    WT.register_checkpoint("sd_xl_tiny.safetensors", lambda: dict(
+        unet=synth.synth_state_dict(ns, seed=1, norm_names=norms), vae=synth.synth_state_dict(vns, seed=3, norm_names=vnorms),
+        clip=G.SyntheticCLIP(ctx_dim=128, pooled_dim=64), unet_cfg=cfg))
+    model, clip, vae = G.CheckpointLoaderSimple().load_checkpoint("sd_xl_tiny.safetensors")
+    (pos,), (neg,) = G.CLIPTextEncode().encode(clip, "a castle"), G.CLIPTextEncode().encode(clip, "blurry")
+    lat = LATENT(samples=torch.zeros(2, 4, 16, 16, device="cuda"))
+    (out,) = G.KSampler().sample(model, 11, 2, 4.0, "euler", "normal", pos, neg, lat)
+    (img,) = G.VAEDecode().decode(vae, out)
+    assert tuple(img.shape) == (2, 128, 128, 3) and bool(torch.isfinite(img).all()) and float(img.std()) > 0
+    with pytest.raises(ValueError, match="pooled_output"):
+        G.KSampler().sample(model, 11, 2, 4.0, "euler", "normal", torch.zeros(1, 77, 128), torch.zeros(1, 77, 128), lat)
+    WT.clear_registry()

@@ -160,3 +160,13 @@ def test_call_order_tickets_serialize_sections_in_call_order():
     boom()
     tw.join(timeout=10)
     assert not tw.is_alive() and seen == ["raised", "another in-flight call failed"]
+
+
+def test_sdxl_encode_adm_matches_the_reference():
+    """sampling.encode_adm_sdxl vs comfy SDXL.encode_adm itself (golden sdxl_adm.npz, made by oracle/gen_golden.py sdxl)"""
+    from stable_renderer_amd.sampling import encode_adm_sdxl
+    d = np.load(os.path.join(GOLD, "sdxl_adm.npz"))
+    pooled = torch.from_numpy(d["pooled"])
+    assert torch.equal(encode_adm_sdxl(pooled, 1024, 1024), torch.from_numpy(d["adm_default"]))
+    got = encode_adm_sdxl(pooled, 832, 1216, crop_w=8, crop_h=16, target_width=1024, target_height=1024)
+    assert torch.equal(got, torch.from_numpy(d["adm_custom"])) and tuple(got.shape) == (2, 2816)
