@@ -29,6 +29,7 @@ typedef enum { SR_F16 = 0, SR_F32 = 1 } sr_dtype;
 
 const char* sr_last_error(void);          /* thread-local text of the last failure */
 int sr_version(void);
+const char* sr_source_hash(void);          /* sha256 of the sources / headers / build flags the binary was made from */
 int sr_device_sync(void);                  /* hipDeviceSynchronize (tests only) */
 
 /* ---------------------------------------------------------------------------------------------------
@@ -132,8 +133,11 @@ int sr_cast(const void* x, int32_t src_dtype, void* y, int32_t dst_dtype, int64_
 int sr_softmax_rows(void* x, int32_t rows, int32_t cols, int32_t dtype, void* stream);   /* in place; VAE mid attention */
 /* y[j] = x[sel[j]] for j < nsel, rows of row_bytes bytes (multiple of 16); `sel` is a DEVICE int32 array read at run
  * time, so a captured plan stays valid when the injected frame changes: random_k = k_context[_random_frame_indices]
- * (OverlapCorresponder.pre_atten_inject, corresponder.py:207-214). */
-int sr_gather_rows(const void* x, const int32_t* sel, void* y, int32_t nsel, int64_t row_bytes, void* stream);
+ * (OverlapCorresponder.pre_atten_inject, corresponder.py:207-214).  x holds n_rows rows: an index outside [0, n_rows) is
+ * never dereferenced -- its output row is zero-filled and *err_flag (optional DEVICE int32, sticky) is set to 1, which the
+ * host turns into the IndexError the reference's k_context[idx] raises. */
+int sr_gather_rows(const void* x, const int32_t* sel, void* y, int32_t nsel, int32_t n_rows, int64_t row_bytes,
+                   int32_t* err_flag, void* stream);
 /* y = a + s*b (dtype tensors): apply_control (openaimodel.py:374-386), guided-hint add (cldm.py:297-300) */
 int sr_add_scaled(const void* a, const void* b, void* y, int64_t n, float s, int32_t dtype, void* stream);
 
@@ -161,7 +165,7 @@ typedef struct {
     struct { const void* x; void* y; const float* per_batch_scale; int32_t B, C, HW, Cpad, dtype, ldc; float scale; } cvt;
     struct { const float* t; void* y; int32_t B, dim, dtype; } temb;
     struct { const void* x; void* y; int64_t n; int32_t dtype; int32_t rows, cols; } ew;
-    struct { const void* x; void* y; const int32_t* sel; int64_t row_bytes; int32_t nsel; } gather;
+    struct { const void* x; void* y; const int32_t* sel; int64_t row_bytes; int32_t nsel; int32_t n_rows; int32_t* err_flag; } gather;
     struct { const void* a; const void* b; void* y; int64_t n; float s; int32_t dtype; } add;
   } u;
 } sr_op;
@@ -202,13 +206,23 @@ int sr_idmap_masks(const int32_t* ids, float* masks, int64_t n_pixels, void* str
  * Two-pass, no atomics on the winner: deterministic = sequential "last writer wins". */
 int sr_overlap_build(const int32_t* ids, int32_t N, int32_t H, int32_t W, int32_t lh, int32_t lw,
                      int32_t* pix_cell, int32_t* cell_vid, int32_t* max_vid, void* stream);
+/* Second build phase, after the caller has read max_vid back: CSR of vertexID -> the latent cells of EVERY valid pixel that
+ * carries it (one entry per pixel, so a cell seen through 64 pixels counts 64 times, exactly as the rows of
+ * create_vertex_screen_info do).  vid_off: vid_capacity+1 ints (exclusive prefix sum of the per-vertex pixel counts),
+ * entries: one int per valid pixel (info[2] of sr_overlap_build), scratch: sr_overlap_csr_scratch_ints(vid_capacity) ints.
+ * Integer atomics only (counts, cursors): the order of the entries inside a segment may differ between runs, nothing the
+ * step computes depends on it. */
+int64_t sr_overlap_csr_scratch_ints(int32_t vid_capacity);
+int sr_overlap_csr(const int32_t* ids, const int32_t* pix_cell, int32_t N, int32_t H, int32_t W, int32_t vid_capacity,
+                   int32_t* vid_off, int32_t* entries, int32_t* scratch, void* stream);
 /* One OverlapCorresponder.step_finished (corresponder.py:298-376) on x (N,C,lh,lw) fp32, in place:
- * per-vertex mean of the gathered cells (each id pixel counts once), blend (1-r)*v + r*mean into the
- * winning row's cell, then AdaIN(content = x, style = blended) per (n,c) (math_utils.py:55-80).
- * vsum: scratch (vid_capacity*(C+1)) floats, zeroed by the call.  stats: scratch N*C*4 floats. */
-int sr_overlap_step(float* x, const int32_t* ids, const int32_t* pix_cell, const int32_t* cell_vid,
-                    int32_t N, int32_t C, int32_t H, int32_t W, int32_t lh, int32_t lw, int32_t vid_capacity,
-                    float ratio, float* vsum, float* blended, float* stats, void* stream);
+ * per latent cell, the mean over all pixels carrying the cell's winning vertexID of the latent they gather (each id pixel counts
+ * once; tensor_group_by_then_average, math_utils.py:86-161), blend (1-r)*v + r*mean, then AdaIN(content = x, style = blended)
+ * per (n,c) (math_utils.py:55-80).  No floating-point atomics: the segment sum is exact 2^-28 fixed point in int64 and the
+ * statistics are fixed-order reductions, so the result is bit-reproducible.  blended: (N,C,lh,lw) fp32, written by the call
+ * (the style tensor of the AdaIN; also what tests read). */
+int sr_overlap_step(float* x, const int32_t* cell_vid, const int32_t* vid_off, const int32_t* entries, int32_t N, int32_t C,
+                    int32_t lh, int32_t lw, int32_t vid_capacity, float ratio, float* blended, void* stream);
 
 /* adaptive_instance_normalization NCHW fp32 (math_utils.py:27-80): out = (c-mean_c)/std_c*std_s+mean_s,
  * std = sqrt(unbiased var + eps).  content (N,C,HWc), style (N,C,HWs) with element strides so NHWC inputs

@@ -125,7 +125,20 @@ def sec_idmap():
     with quiet():
         m = cm.IDMap(tensor=ids.clone())
         vsi = m.create_vertex_screen_info()
-    save("idmap", ids=ids, masks=m.masks, vsi=vsi, height_prop=m.height, width_prop=m.width)
+    # SURVEY 8c golden (3), second half: two frames of the reference's own dumped sphere id maps
+    # (resources/example-sphere-and-object-views/sphere/id, legacy int16 layout (obj, mat, texX, texY)), remapped to the current
+    # layout as (obj, mat, 0, texY*1024 + texX) and cropped to a 128x128 window that holds background, silhouette and interior
+    real = []
+    for fr in (11, 25):
+        a = np.load(f"/root/reference/resources/example-sphere-and-object-views/sphere/id/id_{fr}.npy").astype(np.int32)
+        a = a[32:160, 32:160]
+        real.append(np.stack([a[..., 0], a[..., 1], np.zeros_like(a[..., 0]), a[..., 3] * 1024 + a[..., 2]], -1))
+    real = torch.from_numpy(np.stack(real))
+    with quiet():
+        mr = cm.IDMap(tensor=real.clone())
+        vsir = mr.create_vertex_screen_info()
+    save("idmap", ids=ids, masks=m.masks, vsi=vsi, height_prop=m.height, width_prop=m.width,
+         sphere_ids=real, sphere_masks=mr.masks, sphere_vsi=vsir)
 
 
 def sec_overlap():
@@ -411,7 +424,15 @@ def sec_sdxl():
         pooled = rnd(8, 2, 1280)
         a1 = mb.SDXL.encode_adm(stub, pooled_output=pooled, width=1024, height=1024)
         a2 = mb.SDXL.encode_adm(stub, pooled_output=pooled, width=832, height=1216, crop_w=8, crop_h=16, target_width=1024, target_height=1024)
-        save("sdxl_adm", pooled=pooled, adm_default=a1, adm_custom=a2)
+        # latent scaling of the two model families (comfy/latent_formats.py SD15 / SDXL process_in / process_out), picked by
+        # comfy/supported_models.py (SD15.latent_format = SD15, SDXL.latent_format = SDXL)
+        import comfy.latent_formats as lf
+        import comfy.supported_models as sm
+        lat = rnd(9, 1, 4, 8, 8)
+        save("sdxl_adm", pooled=pooled, adm_default=a1, adm_custom=a2, lat=lat,
+             sdxl_in=sm.SDXL.latent_format().process_in(lat), sdxl_out=sm.SDXL.latent_format().process_out(lat),
+             sd15_in=sm.SD15.latent_format().process_in(lat), sd15_out=sm.SD15.latent_format().process_out(lat),
+             sdxl_scale=np.float64(lf.SDXL().scale_factor), sd15_scale=np.float64(lf.SD15().scale_factor))
 
 
 def sec_vae():

@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE (container side; reads /root/reference, never runs on the GPU box).
+
+Pins oracle/raster_ref.c to G-buffers the reference itself dumped with its OpenGL pass:
+``/root/reference/resources/example-sphere-and-object-views/sphere/{pos,id}/*.npy`` — 512x512 frames of a 32-segment
+``Mesh.Sphere`` (engine/static/mesh/mesh.py:518-569), ``pos`` = the FS's ``outPos`` (view-space position,
+default_Gbuffer.frag.glsl:108), ``id`` = the legacy id layout ``(obj, mat, texX, texY)`` int16
+(legacy_codes/stable_rendering_algo/data_classes/correspondence_map.py:279), rows already flipped to image order by
+``Texture.tensor(flip=True)`` (engine/static/texture/texture.py:221-254).
+
+The dumps carry no scene file, so the script RECOVERS the scene from the data and then checks that the oracle, given
+that scene, reproduces the dump:
+  1. projection: least squares of pixel column/row against pos.x/-pos.z, pos.y/-pos.z -> focal length in pixels and
+     principal point.  Pins fov (45 deg: 256/tan(22.5 deg) = 618.0387), the pixel-centre convention (x + 0.5) and the
+     row flip (row 0 = top) of raster_ref.c.
+  2. model-view: sphere centre + radius from |pos - c| = r (the facets sag 1.5*(1-cos(5.6 deg)) inside r = 1.5), rotation
+     from the ids: texX = int(u*1024), texY = int(v*1024) give the object-space direction of every pixel; Kabsch against
+     the view-space direction, refined against the oracle's own interpolated uv so that facet-interpolation error cancels.
+  3. verdict: render the sphere with raster_ref.c under the recovered MV / P and compare coverage (IoU), pos (abs err) and
+     texX / texY (texels) with the dump.
+Writes tests/golden/raster_pin.npz: recovered matrices, the recorded agreement, and a subsample of the reference planes
+(every 4th row: pos fp32, id int16; full-resolution coverage bit mask) that tests/test_raster_pin.py re-checks against
+the oracle (CPU) and tests/test_gpu_raster.py against the HIP rasterizer (GPU).
+
+Run:  python oracle/pin_raster.py        (needs /root/reference; a few seconds)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+REF = "/root/reference/resources/example-sphere-and-object-views/sphere"
+FRAMES = (0, 11, 25, 41)
+TEX = 1024                      # texX / texY quantisation of the legacy id layout
+ROW_STRIDE = 4
+
+
+def obj_dir(u, v):
+    """Mesh.Sphere parametrisation (mesh.py:537-545): uv -> unit position"""
+    return np.stack([np.cos(2 * np.pi * u) * np.sin(np.pi * v), np.cos(np.pi * v), np.sin(2 * np.pi * u) * np.sin(np.pi * v)], -1)
+
+
+def kabsch(a, b, w=None):
+    """rotation R (det +1) minimising sum w |R a - b|^2"""
+    w = np.ones(len(a)) if w is None else w
+    Hm = (a * w[:, None]).T @ b
+    U, _, Vt = np.linalg.svd(Hm)
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(Vt.T @ U.T))])
+    return Vt.T @ D @ U.T
+
+
+def render(mesh_uv, mesh_vu, MV, P, W=512, H=512):
+    """-> (coverage, pos, texX, texY) from raster_ref.c: two draws of the same geometry (ids int(u*1024); with swapped uvs int(v*1024))"""
+    import raster_ref as R
+    from stable_renderer_amd import scene as S
+    out = []
+    for mesh, idw in ((mesh_uv, TEX), (mesh_vu, TEX)):
+        g = R.GBufferRef(W, H)
+        g.clear()
+        t = S.DrawTask(mesh, np.eye(4, dtype=np.float32), sprite_id=1, material_id=1, render_mode=0, use_texcoord_id=True,
+                       id_size=(idw, 0))
+        un = dict(MV=MV.reshape(-1), MV_IT=S.inverse_transpose(MV).reshape(-1), P=P.reshape(-1), depth_test=1)
+        g.draw(t, un)
+        out.append(g)
+    cov = out[0].id[..., 0] != 0
+    return cov, out[0].pos.copy(), out[0].id[..., 3].copy(), out[1].id[..., 3].copy()
+
+
+def sphere_meshes():
+    from stable_renderer_amd import scene as S
+    m = S.Mesh.Sphere(32)
+    m2 = S.Mesh(m.positions, m.normals, m.uvs[:, ::-1].copy(), m.tris)
+    return m, m2
+
+
+def make_mv(R3, c, r):
+    """[col][row] 4x4 float32 = T(c) * R * S(r)"""
+    M = np.eye(4)
+    M[:3, :3] = R3 * r
+    M[:3, 3] = c
+    return M.T.astype(np.float32).copy()           # store column-major rows = glm m[col][row]
+
+
+def fit_frame(fr, mesh_uv, mesh_vu, P, verbose=True):
+    pos = np.load(f"{REF}/pos/pos_{fr}.npy").astype(np.float64)
+    ids = np.load(f"{REF}/id/id_{fr}.npy").astype(np.int64)
+    cov = (ids != 0).any(-1)
+    assert np.array_equal(cov, (pos != 0).any(-1))
+    ys, xs = np.nonzero(cov)
+    pc, ic = pos[cov], ids[cov]
+    # 1. projection
+    fx = np.linalg.lstsq(np.stack([pc[:, 0] / -pc[:, 2], np.ones(len(pc))], 1), xs.astype(np.float64), rcond=None)[0]
+    fy = np.linalg.lstsq(np.stack([pc[:, 1] / -pc[:, 2], np.ones(len(pc))], 1), ys.astype(np.float64), rcond=None)[0]
+    # 2. sphere centre (radius of the circumscribed sphere is the mesh scale: the fit sees the sagging facets)
+    A = np.concatenate([2 * pc, np.ones((len(pc), 1))], 1)
+    sol = np.linalg.lstsq(A, (pc ** 2).sum(1), rcond=None)[0]
+    c = sol[:3]
+    r_fit = float(np.sqrt(sol[3] + c @ c))
+    r = round(r_fit * 2 + 0.02) / 2.0 if abs(r_fit - 1.5) < 0.02 else r_fit      # 1.4915 fitted -> scale 1.5
+    n_view = (pc - c) / np.linalg.norm(pc - c, axis=1, keepdims=True)
+    u, v = (ic[:, 2] + 0.5) / TEX, (ic[:, 3] + 0.5) / TEX
+    wgt = np.sin(np.pi * v) ** 2                                                  # poles: uv interpolation is far from spherical
+    R3 = kabsch(obj_dir(u, v), n_view, wgt)
+    c_try = c.copy()
+    best = None
+    for it in range(8):                              # refine against the oracle's own facet-interpolated uv and positions
+        MV = make_mv(R3, c_try, r)
+        ocov, opos, otx, oty = render(mesh_uv, mesh_vu, MV, P)
+        both = cov & ocov
+        dxi = np.abs(otx[both] - ids[..., 2][both])
+        dxi = np.minimum(dxi, TEX - dxi)
+        dyi = np.abs(oty[both] - ids[..., 3][both])
+        score = float(((dxi <= 1) & (dyi <= 1)).mean())
+        if best is None or score > best[0]:
+            best = (score, R3.copy(), c_try.copy())
+        d_dump = obj_dir((ids[..., 2][both] + 0.5) / TEX, (ids[..., 3][both] + 0.5) / TEX)
+        d_orc = obj_dir((otx[both] + 0.5) / TEX, (oty[both] + 0.5) / TEX)
+        # inliers only: the unreferenced seam column (u in [31/32, 1), mesh.py:555-558) and the pole fan hold texels that are
+        # many texX apart for a sub-pixel shift; they would bias the rotation about the pole axis
+        ok = (np.linalg.norm(d_dump - d_orc, axis=1) < 0.2) if it < 2 else ((dxi <= 2) & (dyi <= 2))
+        w2 = np.sin(np.pi * (ids[..., 3][both] + 0.5) / TEX) ** 2 * ok
+        dR = kabsch(d_dump, d_orc, w2)               # object-space correction: the dump's surface point sits where d_orc is
+        R3 = R3 @ dR
+        c_try = c_try + np.median(pos[both] - opos[both].astype(np.float64), axis=0)
+    _, R3, c_try = best
+    MV = make_mv(R3, c_try, r)
+    ocov, opos, otx, oty = render(mesh_uv, mesh_vu, MV, P)
+    both = cov & ocov
+    iou = both.sum() / float((cov | ocov).sum())
+    perr = np.abs(pos[both] - opos[both]).max()
+    dx = otx[both].astype(np.int64) - ids[..., 2][both]
+    dy = oty[both].astype(np.int64) - ids[..., 3][both]
+    dxw = np.minimum(np.abs(dx), TEX - np.abs(dx))                                # u wraps
+    stats = dict(frame=fr, focal_x=fx[0], cx=fx[1], focal_y=fy[0], cy=fy[1], radius_fit=r_fit, iou=iou,
+                 cov_ref=int(cov.sum()), cov_oracle=int(ocov.sum()), cov_xor=int((cov ^ ocov).sum()), pos_max_abs=float(perr),
+                 tex_within1=float(((dxw <= 1) & (np.abs(dy) <= 1)).mean()), tex_within2=float(((dxw <= 2) & (np.abs(dy) <= 2)).mean()),
+                 texx_mean_abs=float(dxw.mean()), texy_mean_abs=float(np.abs(dy).mean()))
+    if verbose:
+        print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()})
+    return MV, stats, cov, pos, ids
+
+
+def main():
+    from stable_renderer_amd import scene as S
+    P = S.perspective(np.radians(45.0), 1.0, 0.1, 100.0)
+    mesh_uv, mesh_vu = sphere_meshes()
+    out = dict(P=P, frames=np.asarray(FRAMES), tex=np.asarray(TEX), row_stride=np.asarray(ROW_STRIDE))
+    keys = None
+    for fr in FRAMES:
+        MV, st, cov, pos, ids = fit_frame(fr, mesh_uv, mesh_vu, P)
+        out[f"MV_{fr}"] = MV
+        keys = [k for k in st if k != "frame"]
+        out[f"stats_{fr}"] = np.asarray([st[k] for k in keys], np.float64)
+        out[f"cov_{fr}"] = np.packbits(cov)
+        rows = np.arange(0, 512, ROW_STRIDE)
+        sub = cov[rows]
+        out[f"pos_{fr}"] = pos[rows][sub].astype(np.float32)
+        out[f"id_{fr}"] = ids[rows][sub].astype(np.int16)
+    out["stat_keys"] = np.asarray(keys)
+    dst = os.path.join(ROOT, "tests", "golden", "raster_pin.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

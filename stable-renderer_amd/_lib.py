@@ -53,7 +53,7 @@ class _Ew(C.Structure):
 
 
 class _Gather(C.Structure):
-    _fields_ = [("x", vp), ("y", vp), ("sel", vp), ("row_bytes", i64), ("nsel", i32)]
+    _fields_ = [("x", vp), ("y", vp), ("sel", vp), ("row_bytes", i64), ("nsel", i32), ("n_rows", i32), ("err_flag", vp)]
 
 
 class _Add(C.Structure):
@@ -88,6 +88,7 @@ P = C.POINTER
 SYMBOLS = {
     "sr_last_error": (C.c_char_p, []),
     "sr_version": (C.c_int, []),
+    "sr_source_hash": (C.c_char_p, []),
     "sr_device_sync": (C.c_int, []),
     "sr_igemm": (C.c_int, [P(IgemmArgs), vp]),
     "sr_groupnorm": (C.c_int, [P(GroupNormArgs), vp]),
@@ -101,7 +102,7 @@ SYMBOLS = {
     "sr_silu": (C.c_int, [vp, vp, i64, i32, vp]),
     "sr_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
     "sr_softmax_rows": (C.c_int, [vp, i32, i32, i32, vp]),
-    "sr_gather_rows": (C.c_int, [vp, vp, vp, i32, i64, vp]),
+    "sr_gather_rows": (C.c_int, [vp, vp, vp, i32, i32, i64, vp, vp]),
     "sr_add_scaled": (C.c_int, [vp, vp, vp, i64, f32, i32, vp]),
     "sr_plan_run": (C.c_int, [P(Op), i32, vp]),
     "sr_plan_capture": (C.c_int, [P(Op), i32, vp, P(vp)]),
@@ -115,7 +116,9 @@ SYMBOLS = {
     "sr_axpby": (C.c_int, [vp, vp, i64, f32, f32, vp]),
     "sr_idmap_masks": (C.c_int, [vp, vp, i64, vp]),
     "sr_overlap_build": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
-    "sr_overlap_step": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "sr_overlap_csr_scratch_ints": (i64, [i32]),
+    "sr_overlap_csr": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "sr_overlap_step": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
     "sr_legacy_overlap": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, vp]),
     "sr_adain": (C.c_int, [vp, i64, i64, i64, i32, vp, i32, i64, i64, i64, i32, vp, i32, i32, f32, vp, vp]),
     "sr_noise_pool": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
@@ -132,18 +135,69 @@ class SrHipError(RuntimeError):
     pass
 
 
+def _build_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sr_build", os.path.join(_HERE, "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _load():
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)          # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
 def lib():
-    """Load (once) and return the ctypes library; raises if it has not been built (see __graft_entry__.build)."""
+    """Load (once) and return the ctypes library.  The binary must have been built from the sources lying next to it
+    (sr_source_hash() == hash of csrc/*.hip, headers, build flags): a missing or stale library is rebuilt when hipcc is there
+    and refused otherwise -- it is never loaded silently (a stale .so was tested once: commit e818dd3)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise SrHipError("libsr_hip.so not built: run `python stable-renderer_amd/csrc/build.py` "
-                             "(or __graft_entry__.build()); there is no CPU fallback for the product path")
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)          # AttributeError if the symbol is missing: loud by design
-            fn.restype = res
-            fn.argtypes = args
+        bm = _build_module()
+        want = bm.source_hash()
+        have = None
+        if os.path.exists(LIB_PATH):
+            try:
+                have = C.CDLL(LIB_PATH).sr_source_hash
+                have.restype = C.c_char_p
+                have = have().decode()
+            except (OSError, AttributeError):
+                have = None
+        if have != want:
+            if os.environ.get("SR_NO_REBUILD") == "1":
+                raise SrHipError(f"libsr_hip.so is stale or missing (built from {have}, sources are {want}) and SR_NO_REBUILD=1; "
+                                 "there is no CPU fallback for the product path")
+            try:
+                bm.build()
+            except Exception as e:         # no hipcc, compile error: there is no CPU fallback for the product path
+                raise SrHipError(f"libsr_hip.so is stale or missing (built from {have}, sources are {want}) and the rebuild "
+                                 f"failed: {e}\nrun `python stable-renderer_amd/csrc/build.py`; there is no CPU fallback for the "
+                                 "product path") from e
+            if not os.path.exists(LIB_PATH):
+                raise SrHipError(f"{LIB_PATH} not built; there is no CPU fallback for the product path")
+            if have is not None:
+                # the stale image is already mapped into this process (dlopen caches by path): load the new one under a fresh name
+                import shutil
+                import tempfile
+                tmp = os.path.join(tempfile.gettempdir(), f"libsr_hip_{want}_{os.getpid()}.so")
+                shutil.copy2(LIB_PATH, tmp)
+                L = C.CDLL(tmp)
+                for name, (res, args) in SYMBOLS.items():
+                    fn = getattr(L, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                if L.sr_source_hash().decode() != want:
+                    raise SrHipError("rebuilt libsr_hip.so still does not match its sources")
+                _lib = L
+                return _lib
+        L = _load()
+        if L.sr_source_hash().decode() != want:
+            raise SrHipError("libsr_hip.so does not match its sources after the rebuild")
         _lib = L
     return _lib
 

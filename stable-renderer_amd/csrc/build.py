@@ -14,10 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 EXTRA = {"raster.hip": ["-ffp-contract=off"],
          # softmax row maxima never see a NaN (masked scores are -inf, every tile has a valid key): drop the canonicalising
          # v_max x,x the compiler otherwise adds around every fmaxf in the VALU-bound loop
-         "attention.hip": ["-fno-honor-nans"],
-         # overlap_accum's float atomicAdd targets plain device memory (torch / hipMalloc allocations): let it be the native
-         # global_atomic_add_f32 instead of a compare-and-swap loop
-         "overlap.hip": ["-munsafe-fp-atomics"]}
+         "attention.hip": ["-fno-honor-nans"]}
 HEADERS = ["sr_common.h", os.path.join("..", "..", "include", "sr_hip.h")]
 
 
@@ -26,6 +23,19 @@ def hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     raise RuntimeError("hipcc not found")
+
+
+def source_hash():
+    """sha256 over every source, header and this file (the flags live here): the identity of what libsr_hip.so must contain"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS) + [os.path.basename(__file__)]:
+        fp = os.path.join(HERE, f)
+        if os.path.exists(fp):
+            h.update(f.encode())
+            with open(fp, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:32]
 
 
 def _needs(src, obj):
@@ -41,10 +51,13 @@ def build(force=False, verbose=False):
     cc = hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     jobs = []
+    sh = source_hash()
+    stamp = os.path.join(OBJ, "src.hash")
+    stale_stamp = not os.path.exists(stamp) or open(stamp).read().strip() != sh
     for s in srcs:
         obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
-        if force or _needs(s, obj):
-            cmd = [cc] + FLAGS + EXTRA.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(HERE, s), "-o", obj]
+        if force or _needs(s, obj) or (s == "errors.cpp" and stale_stamp):      # errors.cpp carries the hash
+            cmd = [cc] + FLAGS + EXTRA.get(s, []) + ([f'-DSR_SRC_HASH="{sh}"'] if s == "errors.cpp" else []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(HERE, s), "-o", obj]
             jobs.append((s, cmd))
 
     def run(job):
@@ -61,6 +74,8 @@ def build(force=False, verbose=False):
         r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    with open(stamp, "w") as f:
+        f.write(sh)
     return LIB
 
 

@@ -83,12 +83,20 @@ __global__ void add_scaled_kernel(const T* __restrict__ a, const T* __restrict__
   if (i < n) sr_store_f(y + i, sr_load_f(a + i) + s * sr_load_f(b + i));
 }
 
-__global__ void gather_rows_kernel(const uint4* __restrict__ x, const int* __restrict__ sel, uint4* __restrict__ y, int nsel, int64_t row_chunks) {
+// y[j] = x[sel[j]]; an index outside [0, n_rows) never reaches memory: the row is zero-filled and *err is raised
+__global__ void gather_rows_kernel(const uint4* __restrict__ x, const int* __restrict__ sel, uint4* __restrict__ y, int nsel, int n_rows,
+                                   int64_t row_chunks, int* __restrict__ err) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)nsel * row_chunks) return;
   const int j = (int)(i / row_chunks);
   const int64_t c = i - (int64_t)j * row_chunks;
-  y[i] = x[(int64_t)sel[j] * row_chunks + c];
+  const int r = sel[j];
+  if (r < 0 || r >= n_rows) {
+    y[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (c == 0 && err) atomicOr(err, 1);
+    return;
+  }
+  y[i] = x[(int64_t)r * row_chunks + c];
 }
 
 __global__ void eps_scale_kernel(const float* __restrict__ x, float* __restrict__ xin, int64_t n, int copies, float inv) {
@@ -211,10 +219,13 @@ extern "C" int sr_add_scaled(const void* a, const void* b, void* y, int64_t n, f
   return SR_OK;
 }
 
-extern "C" int sr_gather_rows(const void* x, const int32_t* sel, void* y, int32_t nsel, int64_t row_bytes, void* stream) {
-  if (!x || !sel || !y || row_bytes % 16) SR_FAIL(SR_ERR_INVALID, "sr_gather_rows: bad args");
+extern "C" int sr_gather_rows(const void* x, const int32_t* sel, void* y, int32_t nsel, int32_t n_rows, int64_t row_bytes,
+                              int32_t* err_flag, void* stream) {
+  if (!x || !sel || !y || row_bytes <= 0 || row_bytes % 16 || nsel < 0 || n_rows < 1) SR_FAIL(SR_ERR_INVALID, "sr_gather_rows: bad args");
+  if (nsel == 0) return SR_OK;
   const int64_t rc = row_bytes / 16;
-  hipLaunchKernelGGL(gather_rows_kernel, g1((int64_t)nsel * rc), dim3(256), 0, sr_stream(stream), (const uint4*)x, sel, (uint4*)y, nsel, rc);
+  hipLaunchKernelGGL(gather_rows_kernel, g1((int64_t)nsel * rc), dim3(256), 0, sr_stream(stream), (const uint4*)x, sel, (uint4*)y, nsel, n_rows, rc,
+                     err_flag);
   SR_CHECK_LAUNCH("sr_gather_rows");
   return SR_OK;
 }

@@ -56,18 +56,112 @@ __global__ void overlap_build2(const int4* __restrict__ ids, int ncell, const in
   cell_vid[c] = w >= 0 ? ids[w].w : -1;
 }
 
-__global__ void overlap_accum(const float* __restrict__ x, const int4* __restrict__ ids, const int* __restrict__ pix_cell, int64_t npix,
-                              int C, int lhw, int cap, float* __restrict__ vsum) {
+// ---- vertexID -> entries CSR (built once per call) ---------------------------------------------------------------------------
+// cnt[vid] = number of valid pixels carrying vid (integer atomics: the result does not depend on their order)
+__global__ void overlap_count(const int4* __restrict__ ids, const int* __restrict__ pix_cell, int64_t npix, int cap, int* __restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix || pix_cell[i] < 0) return;
+  const int vid = ids[i].w;
+  if (vid < cap) atomicAdd(&cnt[vid], 1);
+}
+// exclusive prefix sum of n ints in three launches: 1024-element block-local scans + block totals, one block over the totals
+// (sequential chunks with a carry), add back.
+constexpr int SCAN_B = 1024;
+__global__ __launch_bounds__(256) void scan_local(const int* __restrict__ in, int* __restrict__ out, int* __restrict__ bsum, int n) {
+  __shared__ int wsum[4];
+  const int base = blockIdx.x * SCAN_B + threadIdx.x * 4;
+  int v[4], s = 0;
+  for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? in[base + k] : 0; s += v[k]; }
+  int inc = s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int pre = inc - s;
+  for (int w = 0; w < wv; ++w) pre += wsum[w];
+  for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = pre; pre += v[k]; }
+  if (threadIdx.x == 255) bsum[blockIdx.x] = pre;
+}
+__global__ __launch_bounds__(256) void scan_bsum(int* __restrict__ bsum, int nb) {
+  __shared__ int wsum[4];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < nb; c0 += 256) {
+    const int i = c0 + threadIdx.x;
+    const int s = i < nb ? bsum[i] : 0;
+    int inc = s;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int pre = carry_s + inc - s;
+    for (int w = 0; w < wv; ++w) pre += wsum[w];
+    if (i < nb) bsum[i] = pre;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = pre + s;
+    __syncthreads();
+  }
+}
+__global__ void scan_add(int* __restrict__ out, const int* __restrict__ bsum, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += bsum[i / SCAN_B];
+}
+// entries[off[vid] .. off[vid+1]) = latent cells of the pixels carrying vid.  The order inside a segment depends on the
+// cursor atomics; the step sums a segment in exact integer arithmetic, so its result does not.
+__global__ void overlap_fill(const int4* __restrict__ ids, const int* __restrict__ pix_cell, int64_t npix, int cap, const int* __restrict__ off,
+                             int* __restrict__ cursor, int* __restrict__ entries) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   const int cell = pix_cell[i];
   if (cell < 0) return;
   const int vid = ids[i].w;
   if (vid >= cap) return;
+  entries[off[vid] + atomicAdd(&cursor[vid], 1)] = cell;
+}
+
+// ---- per step ---------------------------------------------------------------------------------------------------------------
+// blended[n,c,cell] = (1-r)*x + r*mean over every pixel that carries the cell's winning vertexID (corresponder.py:339-369).
+// Eight lanes per latent cell walk the vertex's segment; the sum is taken in 2^-28 fixed point (int64: exact, so neither the
+// segment order nor the lane split can change a bit of the result; |x| is clamped to 4096, 2^21 pixels of one vertex still fit).
+constexpr float FIX_SCALE = 268435456.0f;                   // 2^28
+__device__ __forceinline__ long long to_fix(float v) {
+  v = fminf(fmaxf(v, -4096.0f), 4096.0f);
+  return (long long)(v * FIX_SCALE);                        // power-of-two scaling is exact; the conversion truncates below 2^-28
+}
+template <int C>
+__global__ __launch_bounds__(256) void overlap_blend(const float* __restrict__ x, const int* __restrict__ cell_vid, const int* __restrict__ off,
+                                                     const int* __restrict__ entries, int ncell, int lhw, int cap, float ratio,
+                                                     float* __restrict__ blended) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int cell = t >> 3, l = t & 7;
+  if (cell >= ncell) return;                                // (whole 8-lane groups leave together)
+  const int vid = cell_vid[cell];
   const int f = cell / lhw, p = cell - f * lhw;
-  float* dst = vsum + (int64_t)vid * (C + 1);
-  for (int c = 0; c < C; ++c) atomicAdd(dst + c, x[((int64_t)f * C + c) * lhw + p]);
-  atomicAdd(dst + C, 1.0f);
+  long long acc[C];
+  for (int c = 0; c < C; ++c) acc[c] = 0;
+  int b = 0, e = 0;
+  if (vid >= 0 && vid < cap) { b = off[vid]; e = off[vid + 1]; }
+  for (int i = b + l; i < e; i += 8) {
+    const int ce = entries[i];
+    const int fe = ce / lhw, pe = ce - fe * lhw;
+    const float* xe = x + (int64_t)fe * C * lhw + pe;
+    for (int c = 0; c < C; ++c) acc[c] += to_fix(xe[(int64_t)c * lhw]);
+  }
+  for (int c = 0; c < C; ++c)
+    for (int o = 1; o < 8; o <<= 1) acc[c] += __shfl_xor(acc[c], o, 8);
+  if (l < C) {
+    long long mine = acc[0];
+    for (int c = 1; c < C; ++c) mine = (l == c) ? acc[c] : mine;
+    const int64_t at = ((int64_t)f * C + l) * lhw + p;
+    const float xv = x[at];
+    float out = xv;
+    if (e > b) {
+      const float mean = (float)((double)mine / ((double)(e - b) * (double)FIX_SCALE));
+      out = (1.0f - ratio) * xv + ratio * mean;
+    }
+    blended[at] = out;
+  }
 }
 
 // block reduction helpers (fixed order -> reproducible)
@@ -81,38 +175,24 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
-// one block per (n, c) plane: blended plane -> stats -> AdaIN -> x (in place)
-__global__ __launch_bounds__(256) void overlap_apply(float* __restrict__ x, const int* __restrict__ cell_vid, const float* __restrict__ vsum,
-                                                     int C, int lhw, int cap, float ratio, float eps, float* __restrict__ blended_out) {
+// one block per (n, c) plane: AdaIN(content = x, style = blended) -> x in place (corresponder.py:371-376)
+__global__ __launch_bounds__(256) void overlap_apply(float* x, const float* __restrict__ blended, int lhw, float eps) {
   __shared__ float red[4];
-  const int n = blockIdx.x / C, c = blockIdx.x - n * C;
   float* xp = x + (int64_t)blockIdx.x * lhw;
-  const int* cv = cell_vid + (int64_t)n * lhw;
-  auto blend = [&](int p) -> float {
-    const float xv = xp[p];
-    const int vid = cv[p];
-    if (vid < 0 || vid >= cap) return xv;
-    const float* s = vsum + (int64_t)vid * (C + 1);
-    const float mean = s[c] / s[C];
-    return (1.0f - ratio) * xv + ratio * mean;
-  };
+  const float* bp = blended + (int64_t)blockIdx.x * lhw;
   float sc = 0.f, ss = 0.f;
-  for (int p = threadIdx.x; p < lhw; p += 256) { sc += xp[p]; ss += blend(p); }
+  for (int p = threadIdx.x; p < lhw; p += 256) { sc += xp[p]; ss += bp[p]; }
   const float mc = block_sum(sc, red) / (float)lhw;
   const float ms = block_sum(ss, red) / (float)lhw;
   float qc = 0.f, qs = 0.f;
   for (int p = threadIdx.x; p < lhw; p += 256) {
-    const float a = xp[p] - mc, b = blend(p) - ms;
+    const float a = xp[p] - mc, b = bp[p] - ms;
     qc += a * a; qs += b * b;
   }
   const float stdc = sqrtf(block_sum(qc, red) / (float)(lhw - 1) + eps);
   const float stds = sqrtf(block_sum(qs, red) / (float)(lhw - 1) + eps);
   __syncthreads();
-  for (int p = threadIdx.x; p < lhw; p += 256) {
-    const float bv = blend(p);
-    if (blended_out) blended_out[(int64_t)blockIdx.x * lhw + p] = bv;
-    xp[p] = (xp[p] - mc) / stdc * stds + ms;
-  }
+  for (int p = threadIdx.x; p < lhw; p += 256) xp[p] = (xp[p] - mc) / stdc * stds + ms;
 }
 
 // generic AdaIN: one block per (n,c)
@@ -325,17 +405,45 @@ extern "C" int sr_overlap_build(const int32_t* ids, int32_t N, int32_t H, int32_
   return SR_OK;
 }
 
-extern "C" int sr_overlap_step(float* x, const int32_t* ids, const int32_t* pix_cell, const int32_t* cell_vid, int32_t N, int32_t C,
-                               int32_t H, int32_t W, int32_t lh, int32_t lw, int32_t cap, float ratio, float* vsum, float* blended,
-                               float* stats, void* stream) {
-  (void)stats;
-  if (!x || !ids || !pix_cell || !cell_vid || !vsum) SR_FAIL(SR_ERR_INVALID, "sr_overlap_step: null");
-  if (lh * lw < 2) SR_FAIL(SR_ERR_INVALID, "sr_overlap_step: latent too small");
+extern "C" int64_t sr_overlap_csr_scratch_ints(int32_t vid_capacity) {
+  const int64_t n = (int64_t)vid_capacity + 1;
+  return n + (n + SCAN_B - 1) / SCAN_B;                      // counts / cursors + block totals of the scan
+}
+
+extern "C" int sr_overlap_csr(const int32_t* ids, const int32_t* pix_cell, int32_t N, int32_t H, int32_t W, int32_t vid_capacity,
+                              int32_t* vid_off, int32_t* entries, int32_t* scratch, void* stream) {
+  if (!ids || !pix_cell || !vid_off || !entries || !scratch || vid_capacity < 1) SR_FAIL(SR_ERR_INVALID, "sr_overlap_csr: bad args");
   hipStream_t st = sr_stream(stream);
-  if (hipMemsetAsync(vsum, 0, (size_t)cap * (C + 1) * sizeof(float), st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "memset");
+  const int n = vid_capacity + 1, nb = (n + SCAN_B - 1) / SCAN_B;
+  int* cnt = scratch;
+  int* bsum = scratch + n;
   const int64_t npix = (int64_t)N * H * W;
-  hipLaunchKernelGGL(overlap_accum, g1(npix), dim3(256), 0, st, x, (const int4*)ids, pix_cell, npix, C, lh * lw, cap, vsum);
-  hipLaunchKernelGGL(overlap_apply, dim3(N * C), dim3(256), 0, st, x, cell_vid, vsum, C, lh * lw, cap, ratio, 1e-5f, blended);
+  if (hipMemsetAsync(cnt, 0, (size_t)n * 4, st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "memset");
+  hipLaunchKernelGGL(overlap_count, g1(npix), dim3(256), 0, st, (const int4*)ids, pix_cell, npix, vid_capacity, cnt);
+  hipLaunchKernelGGL(scan_local, dim3(nb), dim3(256), 0, st, cnt, vid_off, bsum, n);
+  hipLaunchKernelGGL(scan_bsum, dim3(1), dim3(256), 0, st, bsum, nb);
+  hipLaunchKernelGGL(scan_add, g1(n), dim3(256), 0, st, vid_off, bsum, n);
+  if (hipMemsetAsync(cnt, 0, (size_t)n * 4, st) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "memset");
+  hipLaunchKernelGGL(overlap_fill, g1(npix), dim3(256), 0, st, (const int4*)ids, pix_cell, npix, vid_capacity, vid_off, cnt, entries);
+  SR_CHECK_LAUNCH("sr_overlap_csr");
+  return SR_OK;
+}
+
+extern "C" int sr_overlap_step(float* x, const int32_t* cell_vid, const int32_t* vid_off, const int32_t* entries, int32_t N, int32_t C,
+                               int32_t lh, int32_t lw, int32_t vid_capacity, float ratio, float* blended, void* stream) {
+  if (!x || !cell_vid || !vid_off || !entries || !blended) SR_FAIL(SR_ERR_INVALID, "sr_overlap_step: null");
+  if (lh * lw < 2) SR_FAIL(SR_ERR_INVALID, "sr_overlap_step: latent too small");
+  if (C < 1 || C > 8) SR_FAIL(SR_ERR_INVALID, "sr_overlap_step: 1 <= C <= 8");
+  hipStream_t st = sr_stream(stream);
+  const int ncell = N * lh * lw, lhw = lh * lw;
+  const dim3 grid((unsigned)(((int64_t)ncell * 8 + 255) / 256));
+#define SR_BLEND(CC) hipLaunchKernelGGL(overlap_blend<CC>, grid, dim3(256), 0, st, x, cell_vid, vid_off, entries, ncell, lhw, vid_capacity, ratio, blended)
+  switch (C) {
+    case 1: SR_BLEND(1); break; case 2: SR_BLEND(2); break; case 3: SR_BLEND(3); break; case 4: SR_BLEND(4); break;
+    case 5: SR_BLEND(5); break; case 6: SR_BLEND(6); break; case 7: SR_BLEND(7); break; default: SR_BLEND(8); break;
+  }
+#undef SR_BLEND
+  hipLaunchKernelGGL(overlap_apply, dim3(N * C), dim3(256), 0, st, x, blended, lhw, 1e-5f);
   SR_CHECK_LAUNCH("sr_overlap_step");
   return SR_OK;
 }

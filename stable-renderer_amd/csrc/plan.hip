@@ -23,44 +23,56 @@ static int run_op(const sr_op& op, void* stream) {
     case SR_OP_SILU: return sr_silu(op.u.ew.x, op.u.ew.y, op.u.ew.n, op.u.ew.dtype, stream);
     case SR_OP_SOFTMAX_ROWS: return sr_softmax_rows(op.u.ew.y, op.u.ew.rows, op.u.ew.cols, op.u.ew.dtype, stream);
     case SR_OP_ADD_SCALED: return sr_add_scaled(op.u.add.a, op.u.add.b, op.u.add.y, op.u.add.n, op.u.add.s, op.u.add.dtype, stream);
-    case SR_OP_GATHER_ROWS: return sr_gather_rows(op.u.gather.x, op.u.gather.sel, op.u.gather.y, op.u.gather.nsel, op.u.gather.row_bytes, stream);
+    case SR_OP_GATHER_ROWS: return sr_gather_rows(op.u.gather.x, op.u.gather.sel, op.u.gather.y, op.u.gather.nsel, op.u.gather.n_rows, op.u.gather.row_bytes,
+                                                   op.u.gather.err_flag, stream);
     default: sr_set_error("sr_plan_run: unknown op kind %d", op.kind); return SR_ERR_INVALID;
   }
 }
 
-// side lane: one extra stream per process + two events (fork / join).  Re-recording an event is safe here: a wait
-// captures the record that precedes it in program order, eagerly and under stream capture alike.
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_fork = nullptr, g_join = nullptr;
-static int side_init() {
-  if (g_side) return SR_OK;
-  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "side stream");
-  if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess)
-    SR_FAIL(SR_ERR_LAUNCH, "side events");
+// side lane: one extra stream + two events (fork / join) PER MAIN STREAM (calls in flight on several streams each get their
+// own, created under a mutex on the device that is current when the main stream first forks).  Re-recording an event is
+// safe here: a wait captures the record that precedes it in program order, eagerly and under stream capture alike.
+#include <mutex>
+#include <unordered_map>
+struct sr_side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static std::mutex g_side_mu;
+static std::unordered_map<void*, sr_side> g_sides;
+static int side_get(void* main_stream, sr_side* out) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  auto it = g_sides.find(main_stream);
+  if (it == g_sides.end()) {
+    sr_side sd;
+    if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "side stream");
+    if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess)
+      SR_FAIL(SR_ERR_LAUNCH, "side events");
+    it = g_sides.emplace(main_stream, sd).first;
+  }
+  *out = it->second;
   return SR_OK;
 }
 
 extern "C" int sr_plan_run(const sr_op* ops, int32_t n, void* stream) {
   if (!ops || n < 0) SR_FAIL(SR_ERR_INVALID, "sr_plan_run: bad args");
   bool side_open = false;                                    // side-lane work issued since the last JOIN
+  sr_side sd;
   for (int i = 0; i < n; ++i) {
     if (ops[i].kind == SR_OP_FORK || ops[i].kind == SR_OP_JOIN || ops[i].lane == 1) {
-      if (side_init() != SR_OK) return SR_ERR_LAUNCH;
+      if (!sd.s && side_get(stream, &sd) != SR_OK) return SR_ERR_LAUNCH;
     }
     if (ops[i].kind == SR_OP_FORK) {
-      if (hipEventRecord(g_fork, sr_stream(stream)) != hipSuccess || hipStreamWaitEvent(g_side, g_fork, 0) != hipSuccess)
+      if (hipEventRecord(sd.fork, sr_stream(stream)) != hipSuccess || hipStreamWaitEvent(sd.s, sd.fork, 0) != hipSuccess)
         SR_FAIL(SR_ERR_LAUNCH, "sr_plan_run: fork at op %d", i);
       side_open = true;
       continue;
     }
     if (ops[i].kind == SR_OP_JOIN) {
-      if (side_open && (hipEventRecord(g_join, g_side) != hipSuccess || hipStreamWaitEvent(sr_stream(stream), g_join, 0) != hipSuccess))
+      if (side_open && (hipEventRecord(sd.join, sd.s) != hipSuccess || hipStreamWaitEvent(sr_stream(stream), sd.join, 0) != hipSuccess))
         SR_FAIL(SR_ERR_LAUNCH, "sr_plan_run: join at op %d", i);
       side_open = false;
       continue;
     }
     if (ops[i].lane == 1 && !side_open) SR_FAIL(SR_ERR_INVALID, "sr_plan_run: side-lane op %d outside FORK..JOIN", i);
-    const int rc = run_op(ops[i], ops[i].lane == 1 ? (void*)g_side : stream);
+    const int rc = run_op(ops[i], ops[i].lane == 1 ? (void*)sd.s : stream);
     if (rc != SR_OK) {
       char buf[400];
       snprintf(buf, sizeof(buf), "%s", sr_last_error());
@@ -69,7 +81,7 @@ extern "C" int sr_plan_run(const sr_op* ops, int32_t n, void* stream) {
     }
   }
   if (side_open) {                                           // a plan must not end with the side lane detached
-    if (hipEventRecord(g_join, g_side) != hipSuccess || hipStreamWaitEvent(sr_stream(stream), g_join, 0) != hipSuccess)
+    if (hipEventRecord(sd.join, sd.s) != hipSuccess || hipStreamWaitEvent(sr_stream(stream), sd.join, 0) != hipSuccess)
       SR_FAIL(SR_ERR_LAUNCH, "sr_plan_run: final join");
   }
   return SR_OK;

@@ -294,17 +294,28 @@ class OverlapIndex:
             raise IndexError("id-map pixel maps outside the latent (non-square frame?): index out of bounds")
         self.n_valid = nvalid
         self.cap = max_vid + 1
-        self.vsum = None
+        # vertexID -> pixels CSR (sr_overlap_csr): what the per-step segmented mean walks
+        lib = L.lib()
+        self.vid_off = torch.empty(self.cap + 1, dtype=torch.int32, device=dev)
+        self.entries = torch.empty(max(nvalid, 1), dtype=torch.int32, device=dev)
+        scratch = torch.empty(lib.sr_overlap_csr_scratch_ints(self.cap), dtype=torch.int32, device=dev)
+        L.check(lib.sr_overlap_csr(_p(ids), _p(self.pix_cell), self.N, self.H, self.W, self.cap, _p(self.vid_off), _p(self.entries),
+                                   _p(scratch), stream_ptr()))
+        self.blended = None
 
     def step(self, x, ratio, blended_out=None):
-        """in-place OverlapCorresponder.step_finished body on x (N,C,lh,lw) fp32 contiguous"""
-        assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[2:]) == (self.lh, self.lw)
+        """in-place OverlapCorresponder.step_finished body on x (N,C,lh,lw) fp32 contiguous; blended_out (same shape) receives
+        the blended latent (the AdaIN style tensor) when given"""
+        assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[2:]) == (self.lh, self.lw) and x.shape[0] == self.N
         Cc = x.shape[1]
-        if self.vsum is None or self.vsum.numel() < self.cap * (Cc + 1):
-            self.vsum = torch.empty(self.cap * (Cc + 1), dtype=torch.float32, device=x.device)
-        L.check(L.lib().sr_overlap_step(_p(x), _p(self.ids), _p(self.pix_cell), _p(self.cell_vid), self.N, Cc, self.H,
-                                        self.W, self.lh, self.lw, self.cap, float(ratio), _p(self.vsum), _p(blended_out),
-                                        None, stream_ptr()))
+        bl = blended_out
+        if bl is None:
+            if self.blended is None or self.blended.shape != x.shape:
+                self.blended = torch.empty_like(x)
+            bl = self.blended
+        assert bl.dtype == torch.float32 and bl.is_contiguous() and bl.shape == x.shape
+        L.check(L.lib().sr_overlap_step(_p(x), _p(self.cell_vid), _p(self.vid_off), _p(self.entries), self.N, Cc, self.lh, self.lw,
+                                        self.cap, float(ratio), _p(bl), stream_ptr()))
         return x
 
 
@@ -324,7 +335,7 @@ def noise_pool(noise_f16, alpha_f16, bg_f32):
     H, W = noise_f16.shape[1:3]
     pooled = torch.empty(H // 8, W // 8, 4, dtype=torch.float32, device=noise_f16.device)
     out = torch.empty(1, 4, H // 8, W // 8, dtype=torch.float32, device=noise_f16.device)
-    key = "np" + str(noise_f16.device)
+    key = ("np", str(noise_f16.device), getattr(_tls, "slot", 0))     # per in-flight slot: calls on other streams run this too
     if key not in _WS:
         _WS[key] = torch.empty(2048, dtype=torch.float32, device=noise_f16.device)
     L.check(L.lib().sr_noise_pool(_p(noise_f16), _p(alpha_f16), _p(bg_f32), _p(pooled), _p(out), H, W, _p(_WS[key]), stream_ptr()))

@@ -190,10 +190,12 @@ class PlanBuilder:
         ar.a, ar.b, ar.y, ar.n, ar.s, ar.dtype = O._p(a), O._p(b), O._p(y), a.numel(), s, O.DT[a.dtype]
         self._emit(L.OP_ADD_SCALED, "add", ar)
 
-    def gather_rows(self, x, sel, y, nsel, row_bytes):
-        self.hold(x, sel, y)
+    def gather_rows(self, x, sel, y, nsel, row_bytes, n_rows, err_flag=None):
+        """y[j] = x[sel[j]] (rows of row_bytes bytes, x holds n_rows of them); an out-of-range device index zero-fills its row and
+        sets err_flag (device int32) instead of reading memory"""
+        self.hold(x, sel, y, err_flag)
         a = L._Gather()
-        a.x, a.y, a.sel, a.row_bytes, a.nsel = O._p(x), O._p(y), O._p(sel), row_bytes, nsel
+        a.x, a.y, a.sel, a.row_bytes, a.nsel, a.n_rows, a.err_flag = O._p(x), O._p(y), O._p(sel), row_bytes, nsel, n_rows, O._p(err_flag)
         self._emit(L.OP_GATHER_ROWS, "gather", a)
 
     def take(self):

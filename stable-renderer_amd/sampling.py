@@ -13,6 +13,13 @@ import torch
 from . import ops as O
 
 LATENT_SCALE = 0.18215            # comfy/latent_formats.py SD15.scale_factor
+LATENT_SCALE_SDXL = 0.13025       # comfy/latent_formats.py SDXL.scale_factor
+
+
+def latent_scale_of(unet_cfg):
+    """latent_formats scale of a model family: checkpoints with vector conditioning (adm_in_channels) are the SDXL family
+    (comfy/supported_models.py:153-175 SDXL / SDXLRefiner -> latent_formats.SDXL), everything else here is SD1.x / SD2.x"""
+    return LATENT_SCALE_SDXL if unet_cfg.get("adm_in_channels") else LATENT_SCALE
 SCHEDULER_NAMES = ["normal", "karras", "exponential", "sgm_uniform", "simple", "ddim_uniform"]
 SAMPLER_NAMES = ["euler", "ddim", "ddpm", "lcm"]
 
@@ -142,6 +149,7 @@ class DiffusionRunner:
         self.n_ctx = n_ctx
         self.use_graph = use_graph
         self.ms = ModelSamplingDiscrete()
+        self.latent_scale = latent_scale_of(unet.cfg)   # process_latent_in / process_latent_out (samplers.py:905, :933)
         self._plan = None
         self._inject = "unset"
         dev = unet.device
@@ -310,7 +318,7 @@ class DiffusionRunner:
                     t_inj = torch.tensor(inject, dtype=torch.int64)
                     PAR.broadcast(t_inj, 0, self.shard.group)
                     inject = t_inj.tolist()
-        latent = torch.zeros_like(noise) if latent_image is None else latent_image * LATENT_SCALE
+        latent = torch.zeros_like(noise) if latent_image is None else latent_image * self.latent_scale
         max_denoise = math.isclose(float(self.ms.sigma_max), float(sig[0]), rel_tol=1e-05) or float(sig[0]) > float(self.ms.sigma_max)
         s0 = float(torch.sqrt(1.0 + sig[0] ** 2.0)) if max_denoise else float(sig[0])
         self.x.copy_(noise.to(dev, torch.float32))
@@ -339,5 +347,8 @@ class DiffusionRunner:
                 raise ValueError(sampler)
         out = torch.empty_like(self.x)
         out.zero_()
-        O.axpby(out, self.x, 1.0 / LATENT_SCALE, 0.0)
+        O.axpby(out, self.x, 1.0 / self.latent_scale, 0.0)
+        if p.get("inject_err") is not None and int(p["inject_err"].item()) != 0:      # the run's one host sync (results are due anyway)
+            p["inject_err"].zero_()
+            raise IndexError("injected frame index outside the batch reached sr_gather_rows (k_context[idx], corresponder.py:207-214)")
         return out, inject

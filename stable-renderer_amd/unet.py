@@ -95,8 +95,9 @@ def pack_weights(sd, dtype, device, pad_cin=(), pad_cout=()):
 class BlockLowering:
     """ResBlock / SpatialTransformer / BasicTransformerBlock -> plan ops; shared by the UNet and the ControlNet encoder."""
 
-    def __init__(self, pb, pro, W, shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx=None, sel=None, external=False):
+    def __init__(self, pb, pro, W, shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx=None, sel=None, external=False, sel_err=None):
         self.pb, self.pro, self.W, self.shapes, self.B, self.cfg = pb, pro, W, shapes, B, cfg
+        self.sel_err = sel_err                         # device int32 raised by sr_gather_rows on an out-of-range injected index
         self.emb_s, self.ctx, self.n_ctx, self.inject_idx, self.sel = emb_s, ctx, n_ctx, inject_idx, sel
         self.ldt_ctx = _cdiv(n_ctx, 8) * 8
         # external=True (view-sharded multi-GPU): the injected frame's tokens come from another rank.  The plan is CUT
@@ -203,9 +204,9 @@ class BlockLowering:
             pb.fork()
             with pb.side():
                 if not self.external:
-                    pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size())
+                    pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size(), B, self.sel_err)
                     if st1 is not None:
-                        pb.gather_rows(st1, sel, src_st, nr, HW * 2 * 4)
+                        pb.gather_rows(st1, sel, src_st, nr, HW * 2 * 4, B, self.sel_err)
                 wk, kk = lin("attn1.to_k", src_st)
                 wv, kv = lin("attn1.to_v", src_st)
                 pb.igemm(src, wk, k, Tk, 1, 1, Cc, Cc, **kk)
@@ -285,12 +286,13 @@ class UNet:
             t_in = pb.buf(B, dtype=torch.float32, zero=True)
             ctx = pb.buf(B, n_ctx, cfg["context_dim"], zero=True)
         ldt_ctx = _cdiv(n_ctx, 8) * 8
-        sel = None
+        sel, sel_err = None, None
         if inject_idx is not None:
             if not inject_external and any(int(i) < 0 or int(i) >= B for i in inject_idx):
                 raise IndexError(f"injected frame index out of range for batch {B}: {list(inject_idx)}")
             sel = pb.buf(len(inject_idx), dtype=torch.int32)
             sel.copy_(torch.tensor([int(i) if 0 <= int(i) < B else 0 for i in inject_idx], dtype=torch.int32))
+            sel_err = pb.buf(1, dtype=torch.int32, zero=True)
 
         # ---- time embedding ------------------------------------------------------------------------
         temb = pb.buf(B, mc)
@@ -316,7 +318,7 @@ class UNet:
         emb_s = pb.buf(B, 4 * mc)
         pb.silu(e2, emb_s)                             # every ResBlock applies SiLU first (emb_layers.0)
 
-        low = BlockLowering(pb, pro, W, self.shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx, sel, external=inject_external)
+        low = BlockLowering(pb, pro, W, self.shapes, B, cfg, emb_s, ctx, n_ctx, inject_idx, sel, external=inject_external, sel_err=sel_err)
         resblock, stransformer = low.resblock, low.stransformer
 
         # ---- encoder ---------------------------------------------------------------------------------
@@ -394,5 +396,5 @@ class UNet:
         pb.nhwc_to_nchw(o_nhwc, out, B, oc, hh * ww, oc)
         flops = pb.flops
         step = pb.take()
-        return dict(prologue=pro.take(), step=step, x=x_in, t=t_in, ctx=ctx, y=y_in, out=out, flops=flops, inject=sel,
+        return dict(prologue=pro.take(), step=step, x=x_in, t=t_in, ctx=ctx, y=y_in, out=out, flops=flops, inject=sel, inject_err=sel_err,
                     segments=low.segments + [step], points=low.points)

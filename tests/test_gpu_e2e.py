@@ -252,10 +252,8 @@ def test_calls_in_flight_equal_the_sequential_loop(monkeypatch):
     v2, w2, r2 = bake(2)
 
     def same(va, vb):
-        # the overlap step accumulates with float atomics: two runs of the SAME sequential loop already differ by one fp16 ulp
-        # in ~0.15 % of the baked values (tools/check_inflight.py), so that is the bar here too
-        d = (va.float() - vb.float()).abs()
-        return float(d.max()) <= 2 ** -10 and int((d > 0).sum()) < 0.01 * d.numel()
+        # nothing on the path is order dependent (no float atomics; per-slot scratch): in-flight calls are BIT equal to the loop
+        return torch.equal(va, vb)
     assert int(w1.sum()) > 0 and torch.equal(w1, w2) and same(v1, v2)
     assert torch.equal(r1, r2)                                  # the global generator ends in the same state
     v3, w3, r3 = bake(3)

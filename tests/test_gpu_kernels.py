@@ -409,6 +409,39 @@ def test_idmap_masks_and_overlap_vs_oracle_and_golden(ops):
         assert torch.allclose(out, O.overlap_step(x, d[f"{name}_ids"], m["ratio"]), atol=1e-5, rtol=1e-5)
 
 
+def test_idmap_and_overlap_index_on_reference_sphere_ids(ops):
+    """IDMap masks + the overlap index on two frames of the id maps the reference itself dumped
+    (resources/example-sphere-and-object-views/sphere/id; golden = the reference's IDMap.masks / create_vertex_screen_info)"""
+    d = np.load(os.path.join(GOLD, "idmap.npz"))
+    ids = torch.from_numpy(d["sphere_ids"]).cuda()
+    assert np.array_equal(ops.idmap_masks(ids).cpu().numpy(), d["sphere_masks"])
+    vsi = d["sphere_vsi"]
+    n, H, W = ids.shape[:3]
+    h, w = H // 8, W // 8
+    idx = ops.OverlapIndex(ids, h, w)
+    assert idx.n_valid == len(vsi)
+    sx = (vsi[:, 4] * np.float32(w)).astype(np.int32)
+    sy = (vsi[:, 5] * np.float32(h)).astype(np.int32)
+    cell = (vsi[:, 6].astype(np.int32) * h + sy) * w + sx
+    exp_vid = np.full(n * h * w, -1, np.int32)
+    exp_vid[cell] = vsi[:, 3].astype(np.int32)                   # sequential: last row wins
+    assert np.array_equal(idx.cell_vid.cpu().numpy(), exp_vid)
+    # CSR: segment of vertex v = the cells of the vsi rows carrying v (as a multiset)
+    off, ent = idx.vid_off.cpu().numpy(), idx.entries.cpu().numpy()
+    vids = vsi[:, 3].astype(np.int64)
+    assert np.array_equal(np.diff(off), np.bincount(vids, minlength=idx.cap))
+    order = np.argsort(vids, kind="stable")
+    exp_sorted = np.concatenate([np.sort(c) for c in np.split(cell[order], np.cumsum(np.bincount(vids, minlength=idx.cap))[:-1])])
+    got_sorted = np.concatenate([np.sort(ent[off[v]:off[v + 1]]) for v in range(idx.cap)]) if idx.cap < 5000 else None
+    if got_sorted is not None:
+        assert np.array_equal(got_sorted, exp_sorted)
+    else:                                                        # large vertex ranges: check per-vertex sums of cells instead
+        s_exp = np.bincount(vids, weights=cell.astype(np.float64), minlength=idx.cap)
+        seg = np.repeat(np.arange(idx.cap), np.diff(off))
+        s_got = np.bincount(seg, weights=ent[:off[-1]].astype(np.float64), minlength=idx.cap)
+        assert np.array_equal(s_exp, s_got)
+
+
 def test_overlap_nonsquare_raises(ops):
     ids = torch.ones(1, 48, 32, 4, dtype=torch.int32).cuda()
     with pytest.raises(IndexError):
@@ -466,3 +499,53 @@ def test_sampler_math(ops):
                 nz = torch.randn_like(x0).cuda() if sn > 0 else None
                 ops.lcm_step(xg, dg, nz, sn)
         assert torch.allclose(xg.cpu(), ref, atol=2e-5, rtol=1e-5), sampler
+
+
+def test_gather_rows_rejects_out_of_range_index(ops):
+    """sr_gather_rows never dereferences a device index outside [0, n_rows): the row is zero-filled and the sticky device flag is
+    raised (round 1 recorded a GPU memory fault from exactly this: a global batch index selecting a row of a rank-local batch)"""
+    import ctypes as C
+    from stable_renderer_amd import _lib as L
+    x = rnd(1, 4, 64).cuda()
+    sel = torch.tensor([2, 7, -1, 0, 1 << 30], dtype=torch.int32).cuda()
+    y = torch.full((5, 64), 9.0).cuda()
+    err = torch.zeros(1, dtype=torch.int32).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    L.check(L.lib().sr_gather_rows(p(x), p(sel), p(y), 5, 4, 64 * 4, p(err), ops.stream_ptr()))
+    torch.cuda.synchronize()
+    assert int(err.item()) == 1
+    assert torch.equal(y[0], x[2]) and torch.equal(y[3], x[0])
+    assert not y[1].any() and not y[2].any() and not y[4].any()
+    err.zero_()
+    L.check(L.lib().sr_gather_rows(p(x), p(sel[3:4]), p(y), 1, 4, 64 * 4, p(err), ops.stream_ptr()))
+    assert int(err.item()) == 0
+    assert L.lib().sr_gather_rows(p(x), p(sel), p(y), 5, 0, 64 * 4, p(err), ops.stream_ptr()) != 0       # n_rows is mandatory
+
+
+def test_sampler_raises_when_the_device_side_injected_index_is_bad():
+    """a bad index written to the plan's DEVICE selector (what the host range check cannot see) surfaces as IndexError, no fault"""
+    from stable_renderer_amd import synth
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    from stable_renderer_amd.sampling import DiffusionRunner
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    ns, norms = unet_names_shapes(cfg)
+    net = UNet(synth.synth_state_dict(ns, seed=1, norm_names=norms), cfg, dtype=torch.float32)
+    r = DiffusionRunner(net, 2, 8, 8, 5.0, use_graph=False)
+    g = torch.Generator().manual_seed(0)
+    r.set_conditioning(torch.randn(1, 77, 64, generator=g), torch.randn(1, 77, 64, generator=g))
+    noise = torch.randn(2, 4, 8, 8, generator=g)
+    out, inj = r.sample(noise, 2, "ddim", "normal", inject_n_rand=1)
+    assert torch.isfinite(out).all()
+    orig = r._ensure_plan
+
+    def poisoned(inject):
+        p = orig(inject)
+        p["inject"].fill_(1000)                      # behind the host check's back
+        return p
+    r._ensure_plan = poisoned
+    with pytest.raises(IndexError):
+        r.sample(noise, 2, "ddim", "normal", inject_n_rand=1)
+    r._ensure_plan = orig
+    out2, _ = r.sample(noise, 2, "ddim", "normal", inject_n_rand=1)       # the flag was cleared: the runner stays usable
+    assert torch.isfinite(out2).all()

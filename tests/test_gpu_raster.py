@@ -92,3 +92,25 @@ def test_raster_baked_mode_reads_corrmap():
     assert np.array_equal(gb.id.cpu().numpy(), ref.id)
     assert np.array_equal(gb.color.cpu().numpy().view(np.uint16), ref.color)
     assert np.array_equal(gb.normal_depth.cpu().numpy().view(np.uint16), ref.normal_depth)
+
+
+@pytest.mark.parametrize("fr", (0, 11, 25, 41))
+def test_hip_rasterizer_matches_reference_dump(gold, fr):
+    """the HIP rasterizer against the G-buffers the reference's OpenGL pass dumped (fixture raster_pin.npz, see
+    tests/test_raster_pin.py): coverage IoU, view-space pos, texcoord ids within one texel"""
+    from stable_renderer_amd import scene as S
+    from test_raster_pin import check_against_reference_dump
+    d = gold("raster_pin")
+    m = S.Mesh.Sphere(32)
+    m_vu = S.Mesh(m.positions, m.normals, m.uvs[:, ::-1].copy(), m.tris)
+    MV, P = d[f"MV_{fr}"], d["P"]
+    out = []
+    for mesh in (m, m_vu):
+        gb = S.GBuffer(512, 512)
+        gb.clear()
+        t = S.DrawTask(mesh, MV, use_texcoord_id=True, id_size=(int(d["tex"]), 0))
+        gb.draw(t, np.eye(4, dtype=np.float32), P)               # draw_params: MV = view * model with view = I
+        torch.cuda.synchronize()
+        out.append(gb)
+    cov = (out[0].id[..., 0] != 0).cpu().numpy()
+    check_against_reference_dump(d, fr, cov, out[0].pos.cpu().numpy(), out[0].id[..., 3].cpu().numpy(), out[1].id[..., 3].cpu().numpy())

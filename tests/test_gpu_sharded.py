@@ -14,12 +14,60 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _guarded(body, rank, world, port, q):
+    """worker shell: any failure travels to the parent as ('error', traceback) instead of leaving it blocked on the queue"""
+    import traceback
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            q.put((rank, "ok", body(rank, world)))
+        finally:
+            dist.destroy_process_group()
+    except BaseException:                                   # noqa: BLE001 - reported to the parent
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def _run_ranks(target, world, port, timeout=400):
+    """start `world` ranks, fail fast when one dies or reports an error, never leave children behind"""
+    import queue as _q
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res, t0 = {}, time.time()
+    try:
+        while len(res) < world:
+            try:
+                rank, status, payload = q.get(timeout=2)
+            except _q.Empty:
+                dead = [p for p in ps if p.exitcode not in (None, 0)]
+                assert not dead, f"rank process died with exit code {[p.exitcode for p in dead]} (GPU fault?)"
+                assert time.time() - t0 < timeout, "ranks timed out"
+                continue
+            assert status == "ok", f"rank {rank} failed:\n{payload}"
+            res[rank] = payload
+        for p in ps:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=10)
+    return [res[r] for r in range(world)]
+
+
+def _worker(rank, world, port, q):
+    _guarded(_worker_body, rank, world, port, q)
+
+
+def _worker_body(rank, world):
+    if True:
         from stable_renderer_amd import synth
         from stable_renderer_amd.model_shapes import unet_names_shapes
         from stable_renderer_amd.unet import UNet, SD15_CFG
@@ -64,33 +112,22 @@ def _worker(rank, world, port, q):
         full = sh.gather_latents(mine)
         torch.cuda.synchronize()
         err = (full - base).abs().max().item() / max(1.0, base.abs().max().item())
-        q.put((rank, err, inj0, inj1))
-    finally:
-        dist.destroy_process_group()
+        return (rank, err, inj0, inj1)
 
 
 def test_two_rank_view_shard_matches_single_process():
-    port = 29700 + (os.getpid() % 1000)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=400) for _ in ps]
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_worker, 2, 29700 + (os.getpid() % 1000))
     for rank, err, inj0, inj1 in res:
         assert inj0 == inj1, (inj0, inj1)
         assert err < 1e-4, (rank, err)
 
 
 def _pipe_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
+    _guarded(_pipe_body, rank, world, port, q)
+
+
+def _pipe_body(rank, world):
+    if True:
         from stable_renderer_amd.pipeline import build_sd15_pipeline
         from stable_renderer_amd.parallel import ViewShard
         from stable_renderer_amd.unet import SD15_CFG
@@ -114,24 +151,13 @@ def _pipe_worker(rank, world, port, q):
             w0, w1 = c0._writtens.cpu(), c1._writtens.cpu()
             dv = (c0._values - c1._values).abs().max().item()
             same = (bool((w0 == w1).all()), int(w0.sum()), dv)
-        q.put((rank, err, same))
-    finally:
-        dist.destroy_process_group()
+        return (rank, err, same)
 
 
 def test_two_rank_pipeline_shard_bakes_the_same_corrmap():
     """raster (own views) -> id all-gather -> sharded sampling -> decode -> frames to rank 0 -> ordered corr-map update"""
-    port = 28700 + (os.getpid() % 1000)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=400) for _ in ps]
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_ranks(_pipe_worker, 2, 28700 + (os.getpid() % 1000))
     for rank, err, same in res:
         assert err < 2e-4, (rank, err)
         if rank == 0:
-            assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same      # values are stored fp16: one ulp of rounding flip
+            assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same      # fp16 store of fp32 frames that differ by GEMM batch shape

@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import torch
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -59,11 +60,25 @@ def test_no_cpu_fallback_without_library(monkeypatch):
     from stable_renderer_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsr_hip.so")
+    monkeypatch.setenv("SR_NO_REBUILD", "1")
     try:
         _lib.lib()
         assert False, "must fail loudly"
     except _lib.SrHipError as e:
         assert "no CPU fallback" in str(e)
+
+
+def test_stale_library_is_refused(monkeypatch, tmp_path):
+    """a libsr_hip.so that was not built from the sources next to it is never loaded silently (sr_source_hash vs build.source_hash)"""
+    from stable_renderer_amd import _lib
+    bm = _lib._build_module()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("SR_NO_REBUILD", "1")
+    real = bm.source_hash()
+    monkeypatch.setattr(_lib, "_build_module", lambda: type("B", (), {"source_hash": staticmethod(lambda: "deadbeef" + real[8:]),
+                                                                      "build": staticmethod(lambda: None)}))
+    with pytest.raises(_lib.SrHipError, match="stale or missing"):
+        _lib.lib()
 
 
 def test_scene_math():
@@ -170,3 +185,16 @@ def test_sdxl_encode_adm_matches_the_reference():
     assert torch.equal(encode_adm_sdxl(pooled, 1024, 1024), torch.from_numpy(d["adm_default"]))
     got = encode_adm_sdxl(pooled, 832, 1216, crop_w=8, crop_h=16, target_width=1024, target_height=1024)
     assert torch.equal(got, torch.from_numpy(d["adm_custom"])) and tuple(got.shape) == (2, 2816)
+
+
+def test_latent_scale_follows_the_model_family():
+    """process_latent_in / out scale: 0.18215 for SD1.x, 0.13025 for the SDXL family (golden: comfy's own latent_formats picked
+    through supported_models; the sampler multiplies the latent image by it going in and divides coming out)"""
+    from stable_renderer_amd.sampling import latent_scale_of
+    from stable_renderer_amd.unet import SD15_CFG, SDXL_CFG
+    d = np.load(os.path.join(GOLD, "sdxl_adm.npz"))
+    assert latent_scale_of(SD15_CFG) == float(d["sd15_scale"]) and latent_scale_of(SDXL_CFG) == float(d["sdxl_scale"])
+    lat = torch.from_numpy(d["lat"])
+    assert torch.equal(lat * latent_scale_of(SDXL_CFG), torch.from_numpy(d["sdxl_in"]))
+    assert torch.equal(lat * latent_scale_of(SD15_CFG), torch.from_numpy(d["sd15_in"]))
+    assert torch.allclose(lat / latent_scale_of(SDXL_CFG), torch.from_numpy(d["sdxl_out"]), rtol=1e-6)

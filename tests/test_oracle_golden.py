@@ -49,6 +49,9 @@ def test_idmap(gold):
     d = gold("idmap")
     assert np.array_equal(O.idmap_masks(d["ids"]), d["masks"])
     assert np.array_equal(O.vertex_screen_info(d["ids"]), d["vsi"])
+    # two frames of the reference's own dumped sphere id maps (SURVEY 8c golden 3)
+    assert np.array_equal(O.idmap_masks(d["sphere_ids"]), d["sphere_masks"])
+    assert np.array_equal(O.vertex_screen_info(d["sphere_ids"]), d["sphere_vsi"])
 
 
 def test_overlap_step(gold):

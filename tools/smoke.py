@@ -1,4 +1,4 @@
-"""One small invocation of the whole hot path on cuda:0, checked against the oracle (driver's smoke()).
+"""TEST INFRASTRUCTURE (outside the product package: it imports the oracle).  One small invocation of the whole hot path on cuda:0, checked against the oracle (driver's smoke()).
 
 2 views of the bake_ball scene at 128x128 -> raster (bit-exact ids vs oracle/raster_ref.c) -> pooled noise ->
 tiny SD-topology UNet (fp32 MFMA) 2 ddim steps with latent overlap + K/V injection -> tiny VAE decoder -> corr-map
@@ -10,12 +10,12 @@ import torch
 def run():
     import raster_ref as R                      # oracle (checker only)
     import sr_oracle as ORC
-    from . import scene as S
-    from . import synth
-    from .model_shapes import unet_names_shapes, vae_decoder_names_shapes
-    from .pipeline import BakeBallScene, FramePipeline
-    from .unet import SD15_CFG, UNet
-    from .vae import VAEDecoder
+    from stable_renderer_amd import scene as S
+    from stable_renderer_amd import synth
+    from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes
+    from stable_renderer_amd.pipeline import BakeBallScene, FramePipeline
+    from stable_renderer_amd.unet import SD15_CFG, UNet
+    from stable_renderer_amd.vae import VAEDecoder
     dev = "cuda:0"
     torch.cuda.set_device(0)
     W = H = 128
