@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"],
                     help="replica: every GPU bakes its own 8-view group (weak scaling, no collective); shard: ONE 8-view group "
                          "split over the GPUs with the latent all-gather / K,V-source broadcast over RCCL (strong scaling)")
+    ap.add_argument("--controlnets", action="store_true",
+                    help="attach the depth + normal ControlNet pair driven by the G-buffers (BASELINE config 4's composition)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -93,8 +95,10 @@ def main():
     if a.mode == "shard" and world > 1:
         from stable_renderer_amd.parallel import ViewShard
         shard = ViewShard(a.views)
+    controls = [("depth", 1.0), ("normal", 1.0)] if a.controlnets else None     # BASELINE config 4's pair (miku-control.json)
     pipe = build_sd15_pipeline(dtype=dtype, n_views=a.views, steps=a.denoise_steps, cfg=8.0, use_graph=not a.no_graph,
-                               device="cuda:%d" % local, shard=shard)
+                               device="cuda:%d" % local, shard=shard, controls=controls)
+    pipe.runner.time_comm = shard is not None
     torch.manual_seed(1234 + rank)
 
     def sync():
@@ -118,11 +122,14 @@ def main():
         for _ in range(a.warmup):
             pipe.call()
         sync()
+        if shard is not None:
+            pipe.runner.exposed_comm_ms()                     # drop the warm-up's records
         t0 = time.perf_counter()
         for _ in range(a.steps):
             pipe.call()
         sync()
     dt = max(time.perf_counter() - t0, 1e-9)
+    comm_ms = pipe.runner.exposed_comm_ms() if shard is not None else None     # compute-stream stalls in the K/V-source waits
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -136,8 +143,19 @@ def main():
     # launch of one UNet evaluation / their summed duration, measured with events on the stream they are launched on
     roof = None
     if rank == 0:
-        plan = pipe.runner._plan["step"]
-        sub = plan.subset(L.OP_IGEMM)
+        class _Seq:                                           # a view-sharded step plan is a sequence of cut segments
+            def __init__(self, plans):
+                self.plans = [p_ for p_ in plans if p_.n > 0]
+                self.n = sum(p_.n for p_ in self.plans)
+                self.op_flops = [f for p_ in self.plans for f in p_.op_flops]
+
+            def run(self):
+                for p_ in self.plans:
+                    p_.run()
+        sched = pipe.runner._plan.get("schedule") or []
+        plans = [r[1] for r in sched if r[0] == "run"] or [pipe.runner._plan["step"]]
+        plan = _Seq(plans)
+        sub = _Seq([p_.subset(L.OP_IGEMM) for p_ in plans])
         flops = float(sum(sub.op_flops))
         for _ in range(2):
             sub.run()
@@ -177,7 +195,8 @@ def main():
                                       "update; zero latent + engine noise as the reference bake workflows; one call per step"
                                       % (a.denoise_steps, a.views, a.views),
                           "views_per_call": a.views, "denoise_steps": a.denoise_steps, "resolution": 512, "parallelism": ("one group view-sharded x%d" if shard is not None else "view-group replicas x%d") % world,
-                          "calls_in_flight_per_gpu": inflight},
+                          "calls_in_flight_per_gpu": inflight, "controlnets": ["depth", "normal"] if a.controlnets else []},
+               "exposed_comm_ms_per_denoise_step": None if comm_ms is None else round(comm_ms / max(a.steps * a.denoise_steps, 1), 4),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist is not None:

@@ -185,6 +185,21 @@ int sr_eps_scale_input(const float* x, float* xin, int64_t n_per_copy, int32_t c
  * d = (x - denoised)/sigma (euler derivative, computed BEFORE callbacks as the reference does) */
 int sr_cfg_denoise(const float* x, const float* eps, float* denoised, float* d, int64_t n, int32_t copies,
                    float sigma, float cfg, void* stream);
+/* Conditioning composition: several positive / negative conditionings with masks, strengths and areas
+ * (comfy/samplers.py:50-127 get_area_and_mult, :176-320 calc_cond_uncond_batch).  One GROUP = the entries that run as one
+ * model call: same area (ah, aw, y0, x0) of the (N,C,h,w) latent, `chunks` entries in batch order.
+ *   sr_cond_crop_scale: xin[j*N+n] = x[n, :, y0:y0+ah, x0:x0+aw] / sqrt(sigma^2+1) for every chunk j
+ *   sr_cond_accumulate: for j in batch order: out_kind[area] += (x_crop - eps[j]*sigma) * mult[j]; cnt_kind[area] += mult[j]
+ *                       (kinds[j] 0 = cond, 1 = uncond, DEVICE int32; mult (chunks,N,C,ah,aw) = mask*mask_strength*strength
+ *                       with the 8-cell feathering of mask-less areas; out_* start at 0, cnt_* at 1e-37)
+ *   sr_cfg_combine:     c = out_c/cnt_c, u = out_u/cnt_u, denoised = u + (c-u)*cfg (samplers.py:314-351), d = (x-denoised)/sigma */
+int sr_cond_crop_scale(const float* x, float* xin, int32_t N, int32_t C, int32_t h, int32_t w, int32_t ah, int32_t aw, int32_t y0,
+                       int32_t x0, int32_t chunks, float sigma, void* stream);
+int sr_cond_accumulate(const float* x, const float* eps, const float* mult, const int32_t* kinds, float* out_c, float* cnt_c,
+                       float* out_u, float* cnt_u, int32_t N, int32_t C, int32_t h, int32_t w, int32_t ah, int32_t aw, int32_t y0,
+                       int32_t x0, int32_t chunks, float sigma, void* stream);
+int sr_cfg_combine(const float* x, const float* out_c, const float* cnt_c, const float* out_u, const float* cnt_u, float* denoised,
+                   float* d, int64_t n, float sigma, float cfg, void* stream);
 int sr_euler_step(float* x, const float* d, int64_t n, float dt, void* stream);           /* x += d*dt */
 /* DDPMSampler_step + rescale; noise = host-drawn randn (may be NULL when sigma_next == 0) */
 int sr_ddpm_step(float* x, const float* denoised, const float* noise, int64_t n, float sigma, float sigma_next,

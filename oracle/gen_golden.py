@@ -707,6 +707,79 @@ def sec_gbufdump():
          frame=np.int64(frame), **back)
 
 
+def cond_cases():
+    """inputs of the conditioning-composition golden (SURVEY 8c golden 9), shared with the tests: name -> (pos, neg, cfg scale);
+    an entry = [tensor (1,T,C), extras dict] in ComfyUI's CONDITIONING format"""
+    def c(seed):
+        return rnd(seed, 1, 5, 6)
+
+    def blob(seed, thr):
+        m = torch.nn.functional.avg_pool2d(rnd(seed, 1, 1, 128, 192).abs(), 31, 1, 15)
+        return (m[0] > m.median() * thr).float()                       # (1,128,192) 0/1 blobs
+    box = torch.zeros(1, 128, 192)
+    box[:, 24:100, 40:150] = 1.0
+    return {
+        "multi": ([[c(1), {"strength": 1.3}], [c(2), {"mask": blob(3, 1.0), "mask_strength": 0.7, "set_area_to_bounds": False}]],
+                  [[c(4), {}]], 7.5),
+        "area": ([[c(5), {}], [c(6), {"area": ("percentage", 0.5, 0.5, 0.25, 0.25), "strength": 0.9}]], [[c(7), {}]], 4.0),
+        "bounds": ([[c(8), {}], [c(9), {"mask": box, "mask_strength": 1.0, "set_area_to_bounds": True}]],
+                   [[c(10), {}], [c(11), {"strength": 0.5}]], 6.0),
+        "cfg1": ([[c(12), {}], [c(13), {"mask": blob(14, 0.8), "mask_strength": 1.0, "set_area_to_bounds": False}]], [[c(15), {}]], 1.0),
+    }
+
+
+def sec_conds():
+    """calc_cond_uncond_batch / get_area_and_mult / cond_cat / sampling_function (comfy/samplers.py:50-358) and the list
+    preparation of samplers.sample() (:887-912) with a TOY model: the mult / area / mask / batching arithmetic without a UNet.
+    The toy's output depends on the batch row, so the golden also pins the ORDER in which entries are batched."""
+    import comfy.samplers as cs
+    import comfy.sample as csm
+    calls = []
+
+    class Toy:
+        def memory_required(self, shape):
+            return 0
+
+        def apply_model(self, x, t, c_crossattn=None, transformer_options=None, **kw):
+            b = x.shape[0]
+            calls.append((list(x.shape), list(transformer_options["cond_or_uncond"]), list(transformer_options["positive_cond_indices"])))
+            return (x * 0.5 + c_crossattn.mean(dim=(1, 2)).view(-1, 1, 1, 1) + 0.01 * t.view(-1, 1, 1, 1)
+                    + 0.001 * torch.arange(b, dtype=torch.float32).view(-1, 1, 1, 1))
+    out, meta = {}, {}
+    x = rnd(20, 2, 4, 16, 24)
+    sigma = torch.tensor([3.7, 3.7])
+    out["x"], out["sigma"] = x, sigma
+    for name, (pos, neg, scale) in cond_cases().items():
+        p, n = csm.convert_cond(pos), csm.convert_cond(neg)
+        cs.resolve_areas_and_cond_masks(p, 16, 24, "cpu")
+        cs.resolve_areas_and_cond_masks(n, 16, 24, "cpu")
+        for c_ in p:
+            cs.create_cond_with_same_area_if_none(n, c_)
+        for c_ in n:
+            cs.create_cond_with_same_area_if_none(p, c_)
+        calls.clear()
+        with quiet():
+            cp, up = cs.calc_cond_uncond_batch(Toy(), p, n, x, sigma, {})
+        meta[name] = dict(calls=list(calls), n_pos=len(p), n_neg=len(n), scale=scale,
+                          areas_pos=[list(map(int, e["area"])) if "area" in e else None for e in p],
+                          areas_neg=[list(map(int, e["area"])) if "area" in e else None for e in n])
+        with quiet():
+            res = cs.sampling_function(Toy(), x, sigma, n, p, scale, {})
+        out[f"{name}_cond"], out[f"{name}_uncond"], out[f"{name}_cfg"] = cp, up, res
+        ent = {"pos": [], "neg": []}                              # the INPUT entries, so tests need not import this module
+        for kind, lst in (("pos", pos), ("neg", neg)):
+            for i, (t, ex) in enumerate(lst):
+                out[f"{name}_{kind}{i}_c"] = t
+                e = {k: (list(v) if isinstance(v, tuple) else v) for k, v in ex.items() if k != "mask"}
+                if "mask" in ex:
+                    out[f"{name}_{kind}{i}_mask"] = ex["mask"]
+                    e["has_mask"] = True
+                ent[kind].append(e)
+        meta[name]["entries"] = ent
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save("cond_compose", **out)
+
+
 def sec_workflow():
     """(1) the reference's own Workflow.Load + build_prompt (engine/static/workflow.py) on every shipped example graph: the
     prompt dict, the output-node ids, or the exception type the reference raises for that file; (2) comfy's LoRA key map
@@ -782,7 +855,7 @@ def sec_workflow():
 
 SECTIONS = dict(math=sec_math, idmap=sec_idmap, overlap=sec_overlap, corrmap=sec_corrmap, noisepool=sec_noisepool,
                 sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet, legacy=sec_legacy,
-                gbufdump=sec_gbufdump, workflow=sec_workflow, sdxl=sec_sdxl)
+                gbufdump=sec_gbufdump, workflow=sec_workflow, sdxl=sec_sdxl, conds=sec_conds)
 
 if __name__ == "__main__":
     todo = _ARGV or list(SECTIONS)

@@ -453,7 +453,7 @@ LATENT_SCALE = 0.18215                                     # comfy/latent_format
 
 
 def sample_frames(sd, cfg, noise, pos, neg, ids, steps, cfg_scale, sampler, scheduler, denoise=1.0,
-                  overlap=None, latent=None, seed=None):
+                  overlap=None, latent=None, seed=None, cond_entries=None):
     """noise (N,4,h,w); pos/neg (1,77,C); ids (N,H,W,4) or None; overlap = dict(ratio, stop, n_rand) or None.
     RNG draw order replicates the reference (global torch RNG): custom_ksampler's seed randint, then
     pre_atten_inject's randint on the first attention block, then the sampler's per-step randn_like."""
@@ -476,7 +476,21 @@ def sample_frames(sd, cfg, noise, pos, neg, ids, steps, cfg_scale, sampler, sche
     state = {"idx": None}
     use_cfg = not math.isclose(cfg_scale, 1.0)
 
+    entries = None
+    if cond_entries is not None:                            # (pos entries, neg entries): masks / strengths / areas
+        entries = prepare_cond_entries(cond_entries[0], cond_entries[1], noise.shape[2], noise.shape[3])
+
     def denoise_fn(xx, sigma):
+        if entries is not None:
+            def model_fn(xin, s2, c):
+                inj = None
+                if overlap is not None and overlap.get("n_rand", 1) >= 0:
+                    if state["idx"] is None:
+                        state["idx"] = torch.randint(1, xin.shape[0], (overlap.get("n_rand", 1),))
+                    inj = state["idx"]
+                out = unet_forward(sd, cfg, eps_input(xin, s2), ms.timestep(s2).float(), c, inject_idx=inj)
+                return eps_denoised(xin, out, s2)
+            return sampling_function(model_fn, xx, sigma, entries[1], entries[0], cfg_scale)
         # batch order: uncond chunk first, then cond (samplers.py:230-262)
         if use_cfg:
             xin = torch.cat([xx, xx])
@@ -506,6 +520,142 @@ def sample_frames(sd, cfg, noise, pos, neg, ids, steps, cfg_scale, sampler, sche
 
     out = sample_loop(denoise_fn, x, sig, sampler, cb)
     return out / LATENT_SCALE, state["idx"]                 # process_latent_out (samplers.py:933)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Conditioning composition: several positive / negative conditionings with masks, strengths and areas
+# (comfy/samplers.py: get_area_and_mult :50-127, cond_cat :159-174, calc_cond_uncond_batch :176-320, sampling_function :323-358,
+#  get_mask_aabb / resolve_areas_and_cond_masks :452-540, create_cond_with_same_area_if_none :542-575; sample() :887-912).
+# An entry is a dict: cond (1|N,T,C) tensor, optional mask (Nm,H,W) / mask_strength / set_area_to_bounds / strength /
+# area = (h, w, y, x) in latent cells or ("percentage", h, w, y, x).
+def resolve_entries(entries, h, w):
+    """resolve_areas_and_cond_masks: percentage areas -> cells; masks bilinearly resized to the latent; set_area_to_bounds ->
+    area = bounding box of max|mask| over the batch, at least 8x8"""
+    out = []
+    for e in entries:
+        e = dict(e)
+        a = e.get("area")
+        if a is not None and a[0] == "percentage":
+            e["area"] = (max(1, round(a[1] * h)), max(1, round(a[2] * w)), round(a[3] * h), round(a[4] * w))
+        if e.get("mask") is not None:
+            m = e["mask"].float()
+            if m.dim() == 2:
+                m = m.unsqueeze(0)
+            if m.shape[1] != h or m.shape[2] != w:
+                m = F.interpolate(m.unsqueeze(1), size=(h, w), mode="bilinear", align_corners=False).squeeze(1)
+            if e.get("set_area_to_bounds", False):
+                b = m.abs().max(dim=0).values
+                if not bool((b != 0).any()):
+                    e["area"] = (8, 8, 0, 0)
+                else:
+                    ys, xs = torch.where(b != 0)                       # (torch.where(mask) on a float mask = non-zero)
+                    y0, y1, x0, x1 = int(ys.min()), int(ys.max()), int(xs.min()), int(xs.max())
+                    e["area"] = (max(8, y1 - y0 + 1), max(8, x1 - x0 + 1), y0, x0)
+            e["mask"] = m
+        out.append(e)
+    return out
+
+
+def add_opposite_areas(conds, c):
+    """create_cond_with_same_area_if_none(conds, c): if c has an area and conds holds none with exactly that area, append a
+    copy of c carrying the conditioning tensor of the smallest entry of conds that encloses it (or an area-less one)"""
+    if c.get("area") is None:
+        return
+    ca = c["area"]
+    smallest = None
+    for x in conds:
+        if x.get("area") is not None:
+            a = x["area"]
+            if ca[2] >= a[2] and ca[3] >= a[3] and a[0] + a[2] >= ca[0] + ca[2] and a[1] + a[3] >= ca[1] + ca[3]:
+                if smallest is None or smallest.get("area") is None:
+                    smallest = x
+                elif smallest["area"][0] * smallest["area"][1] > a[0] * a[1]:
+                    smallest = x
+        elif smallest is None:
+            smallest = x
+    if smallest is None:
+        return
+    if smallest.get("area") is not None and tuple(smallest["area"]) == tuple(ca):
+        return
+    o = dict(c)
+    o["cond"] = smallest["cond"]
+    conds.append(o)
+
+
+def area_and_mult(e, x):
+    """get_area_and_mult -> (input_x, mult, area); mask-less areas are feathered over 8 cells towards inner borders"""
+    area = (x.shape[2], x.shape[3], 0, 0) if e.get("area") is None else tuple(int(v) for v in e["area"])
+    strength = float(e.get("strength", 1.0))
+    ix = x[:, :, area[2]:area[0] + area[2], area[3]:area[1] + area[3]]
+    if e.get("mask") is not None:
+        m = e["mask"]
+        assert m.shape[1] == x.shape[2] and m.shape[2] == x.shape[3]
+        m = m[:, area[2]:area[0] + area[2], area[3]:area[1] + area[3]] * float(e.get("mask_strength", 1.0))
+        m = m.unsqueeze(1).repeat(ix.shape[0] // m.shape[0], ix.shape[1], 1, 1)
+    else:
+        m = torch.ones_like(ix)
+    mult = m * strength
+    if e.get("mask") is None:
+        rr = 8
+        if area[2] != 0:
+            for t in range(rr):
+                mult[:, :, t:1 + t, :] *= ((1.0 / rr) * (t + 1))
+        if (area[0] + area[2]) < x.shape[2]:
+            for t in range(rr):
+                mult[:, :, area[0] - 1 - t:area[0] - t, :] *= ((1.0 / rr) * (t + 1))
+        if area[3] != 0:
+            for t in range(rr):
+                mult[:, :, :, t:1 + t] *= ((1.0 / rr) * (t + 1))
+        if (area[1] + area[3]) < x.shape[3]:
+            for t in range(rr):
+                mult[:, :, :, area[1] - 1 - t:area[1] - t] *= ((1.0 / rr) * (t + 1))
+    return ix, mult, area
+
+
+def calc_cond_uncond_batch(model_fn, cond, uncond, x, sigma):
+    """model_fn(input_x (B,4,ah,aw), sigma (B,), ctx (B,T,C)) -> DENOISED prediction (apply_model's return).  Entries whose
+    cropped input has the same shape and token count run as ONE batch, in the reference's order: the batchable entries of
+    [cond..., uncond...] reversed (free memory is never the limit here).  -> (cond_pred, uncond_pred, batches) where batches
+    lists, per model call, [(kind, entry index), ...] in batch order (test hook)."""
+    out_c, cnt_c = torch.zeros_like(x), torch.ones_like(x) * 1e-37
+    out_u, cnt_u = torch.zeros_like(x), torch.ones_like(x) * 1e-37
+    n = x.shape[0]
+    to_run = [(area_and_mult(e, x), 0, ("pos", i), e) for i, e in enumerate(cond or [])]
+    to_run += [(area_and_mult(e, x), 1, ("neg", i), e) for i, e in enumerate(uncond or [])]
+    batches = []
+    while to_run:
+        first = to_run[0]
+        idxs = [i for i in range(len(to_run)) if to_run[i][0][0].shape == first[0][0].shape
+                and to_run[i][3]["cond"].shape[1:] == first[3]["cond"].shape[1:]]
+        idxs.reverse()
+        picked = [to_run.pop(i) for i in idxs]
+        xin = torch.cat([p[0][0] for p in picked])
+        ctx = torch.cat([p[3]["cond"].expand(n, -1, -1) for p in picked])
+        sg = torch.cat([sigma] * len(picked))[:len(xin)]
+        out = model_fn(xin, sg, ctx).chunk(len(picked))
+        batches.append([p[2] for p in picked])
+        for o, p in zip(out, picked):
+            (_, mult, a), kind = p[0], p[1]
+            tgt, cnt = (out_c, cnt_c) if kind == 0 else (out_u, cnt_u)
+            tgt[:, :, a[2]:a[0] + a[2], a[3]:a[1] + a[3]] += o * mult
+            cnt[:, :, a[2]:a[0] + a[2], a[3]:a[1] + a[3]] += mult
+    return out_c / cnt_c, out_u / cnt_u, batches
+
+
+def sampling_function(model_fn, x, sigma, uncond, cond, cond_scale):
+    """:323-358: uncond skipped at cfg 1; result = uncond_pred + (cond_pred - uncond_pred) * scale"""
+    c, u, _ = calc_cond_uncond_batch(model_fn, cond, None if math.isclose(cond_scale, 1.0) else uncond, x, sigma)
+    return u + (c - u) * cond_scale
+
+
+def prepare_cond_entries(pos, neg, h, w):
+    """samplers.sample() :887-912 for mask / area entries: resolve both lists, then give every area an opposite entry"""
+    pos, neg = resolve_entries(pos, h, w), resolve_entries(neg, h, w)
+    for c in list(pos):
+        add_opposite_areas(neg, c)
+    for c in list(neg):
+        add_opposite_areas(pos, c)
+    return pos, neg
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -110,6 +110,9 @@ SYMBOLS = {
     "sr_graph_destroy": (C.c_int, [vp]),
     "sr_eps_scale_input": (C.c_int, [vp, vp, i64, i32, f32, vp]),
     "sr_cfg_denoise": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, vp]),
+    "sr_cond_crop_scale": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "sr_cond_accumulate": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "sr_cfg_combine": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, vp]),
     "sr_euler_step": (C.c_int, [vp, vp, i64, f32, vp]),
     "sr_ddpm_step": (C.c_int, [vp, vp, vp, i64, f32, f32, vp]),
     "sr_lcm_step": (C.c_int, [vp, vp, vp, i64, f32, vp]),

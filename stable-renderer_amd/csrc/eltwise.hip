@@ -123,6 +123,51 @@ __global__ void cfg_denoise_kernel(const float* __restrict__ x, const float* __r
   if (d) d[i] = (xv - r) / sigma;                                           // to_d
 }
 
+// ---- conditioning composition (comfy/samplers.py:50-127 get_area_and_mult, :176-320 calc_cond_uncond_batch) -----------------
+// xin[(j*N + n), c, yy, xx] = x[n, c, y0+yy, x0+xx] * inv for every chunk j of the group (all chunks see the same crop)
+__global__ void cond_crop_scale_kernel(const float* __restrict__ x, float* __restrict__ xin, int N, int C, int h, int w, int ah, int aw,
+                                       int y0, int x0, int chunks, float inv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)N * C * ah * aw;
+  if (i >= per) return;
+  const int xx = (int)(i % aw), yy = (int)((i / aw) % ah);
+  const int64_t nc = i / ((int64_t)aw * ah);
+  const float v = x[(nc * h + (y0 + yy)) * w + (x0 + xx)] * inv;
+  for (int j = 0; j < chunks; ++j) xin[(int64_t)j * per + i] = v;
+}
+// for the chunks of one model call, IN BATCH ORDER:  out_kind[area] += (x - eps_j*sigma) * mult_j ; cnt_kind[area] += mult_j
+__global__ void cond_accumulate_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ mult,
+                                       const int* __restrict__ kinds, float* __restrict__ out_c, float* __restrict__ cnt_c,
+                                       float* __restrict__ out_u, float* __restrict__ cnt_u, int N, int C, int h, int w, int ah, int aw,
+                                       int y0, int x0, int chunks, float sigma) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)N * C * ah * aw;
+  if (i >= per) return;
+  const int xx = (int)(i % aw), yy = (int)((i / aw) % ah);
+  const int64_t nc = i / ((int64_t)aw * ah);
+  const int64_t at = (nc * h + (y0 + yy)) * w + (x0 + xx);
+  const float xv = x[at];
+  float oc = out_c[at], cc = cnt_c[at], ou = out_u[at], cu = cnt_u[at];
+  for (int j = 0; j < chunks; ++j) {
+    const float den = xv - eps[(int64_t)j * per + i] * sigma;             // EPS.calculate_denoised on the cropped input
+    const float m = mult[(int64_t)j * per + i];
+    const float t = den * m;                                              // (output * mult) rounded, then added (:309-312)
+    if (kinds[j] == 0) { oc = oc + t; cc = cc + m; } else { ou = ou + t; cu = cu + m; }
+  }
+  out_c[at] = oc; cnt_c[at] = cc; out_u[at] = ou; cnt_u[at] = cu;
+}
+// cond_pred = out_c/cnt_c, uncond_pred = out_u/cnt_u (counts start at 1e-37), cfg = u + (c-u)*scale, d = (x - cfg)/sigma
+__global__ void cfg_combine_kernel(const float* __restrict__ x, const float* __restrict__ out_c, const float* __restrict__ cnt_c,
+                                   const float* __restrict__ out_u, const float* __restrict__ cnt_u, float* __restrict__ den,
+                                   float* __restrict__ d, int64_t n, float sigma, float cfg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float c = out_c[i] / cnt_c[i], u = out_u[i] / cnt_u[i];
+  const float r = u + (c - u) * cfg;
+  den[i] = r;
+  if (d) d[i] = (x[i] - r) / sigma;
+}
+
 __global__ void euler_kernel(float* __restrict__ x, const float* __restrict__ d, int64_t n, float dt) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = x[i] + d[i] * dt;
@@ -243,6 +288,37 @@ extern "C" int sr_cfg_denoise(const float* x, const float* eps, float* den, floa
   if (!x || !eps || !den || (copies != 1 && copies != 2)) SR_FAIL(SR_ERR_INVALID, "sr_cfg_denoise: bad args");
   hipLaunchKernelGGL(cfg_denoise_kernel, g1(n), dim3(256), 0, sr_stream(stream), x, eps, den, d, n, copies, sigma, cfg);
   SR_CHECK_LAUNCH("sr_cfg_denoise");
+  return SR_OK;
+}
+
+extern "C" int sr_cond_crop_scale(const float* x, float* xin, int32_t N, int32_t C, int32_t h, int32_t w, int32_t ah, int32_t aw, int32_t y0,
+                                  int32_t x0, int32_t chunks, float sigma, void* stream) {
+  if (!x || !xin || chunks < 1 || ah < 1 || aw < 1 || y0 < 0 || x0 < 0 || y0 + ah > h || x0 + aw > w)
+    SR_FAIL(SR_ERR_INVALID, "sr_cond_crop_scale: bad args (area outside the latent?)");
+  const float inv = 1.0f / sqrtf(sigma * sigma + 1.0f);
+  hipLaunchKernelGGL(cond_crop_scale_kernel, g1((int64_t)N * C * ah * aw), dim3(256), 0, sr_stream(stream), x, xin, N, C, h, w, ah, aw, y0, x0,
+                     chunks, inv);
+  SR_CHECK_LAUNCH("sr_cond_crop_scale");
+  return SR_OK;
+}
+
+extern "C" int sr_cond_accumulate(const float* x, const float* eps, const float* mult, const int32_t* kinds, float* out_c, float* cnt_c,
+                                  float* out_u, float* cnt_u, int32_t N, int32_t C, int32_t h, int32_t w, int32_t ah, int32_t aw,
+                                  int32_t y0, int32_t x0, int32_t chunks, float sigma, void* stream) {
+  if (!x || !eps || !mult || !kinds || !out_c || !cnt_c || !out_u || !cnt_u || chunks < 1 || ah < 1 || aw < 1 || y0 < 0 || x0 < 0 ||
+      y0 + ah > h || x0 + aw > w)
+    SR_FAIL(SR_ERR_INVALID, "sr_cond_accumulate: bad args (area outside the latent?)");
+  hipLaunchKernelGGL(cond_accumulate_kernel, g1((int64_t)N * C * ah * aw), dim3(256), 0, sr_stream(stream), x, eps, mult, kinds, out_c, cnt_c,
+                     out_u, cnt_u, N, C, h, w, ah, aw, y0, x0, chunks, sigma);
+  SR_CHECK_LAUNCH("sr_cond_accumulate");
+  return SR_OK;
+}
+
+extern "C" int sr_cfg_combine(const float* x, const float* out_c, const float* cnt_c, const float* out_u, const float* cnt_u,
+                              float* denoised, float* d, int64_t n, float sigma, float cfg, void* stream) {
+  if (!x || !out_c || !cnt_c || !out_u || !cnt_u || !denoised) SR_FAIL(SR_ERR_INVALID, "sr_cfg_combine: null");
+  hipLaunchKernelGGL(cfg_combine_kernel, g1(n), dim3(256), 0, sr_stream(stream), x, out_c, cnt_c, out_u, cnt_u, denoised, d, n, sigma, cfg);
+  SR_CHECK_LAUNCH("sr_cfg_combine");
   return SR_OK;
 }
 

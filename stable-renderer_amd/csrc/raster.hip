@@ -380,7 +380,7 @@ extern "C" int sr_raster_draw(const sr_draw* d, const sr_gbuffer* g, void* scrat
   if (!d->pos || !d->normal || !d->tris || d->nt <= 0 || d->nv <= 0) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: mesh arrays missing");
   if (scratch_bytes < sr_raster_scratch_bytes(d->nt, g->W, g->H)) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: scratch too small");
   if (d->render_mode != 0 && d->corrmap_k <= 0) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: corrmap_k");
-  if (d->use_texcoord_id && (d->id_w <= 0 || d->id_h <= 0)) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: id grid size");
+  if (d->use_texcoord_id && (d->id_w <= 0 || d->id_h < 0)) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: id grid size");
   hipStream_t st = sr_stream(stream);
   TriRec* recs = (TriRec*)scratch;
   hipLaunchKernelGGL(raster_setup, dim3((d->nt + 255) / 256), dim3(256), 0, st, *d, recs, g->W, g->H);

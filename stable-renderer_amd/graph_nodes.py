@@ -51,6 +51,28 @@ def _text_encode(clip, text, weight=1.0):
     return [cond, d]
 
 
+def _mask_text_encode(clip, text="", mask=None, inverse_mask=False, strength=1.0, mode="default"):
+    """_nodes/conditions.py:23-50: the text conditioning with a 'mask' / 'mask_strength' / 'set_area_to_bounds' record (what
+    ConditioningSetMask adds, comfyUI/nodes.py:236-262); the sampler resizes the mask to the latent and weights this entry's
+    prediction with it (comfy/samplers.py:76-91)"""
+    if mask is None:
+        return _text_encode(clip, text)
+    cond, pooled = clip.encode_from_tokens(clip.tokenize(text), return_pooled=True)
+    if inverse_mask:
+        mask = 1 - mask
+    if mask.dim() < 3:
+        mask = mask.unsqueeze(0)
+    return [cond, {"pooled_output": pooled, "mask": mask, "set_area_to_bounds": mode == "set_cond_area", "mask_strength": strength}]
+
+
+class MaskedTextEncode(N.StableRenderingNode):
+    """_nodes/conditions.py:52-76: CLIPTextEncode + ConditioningSetMask in one node"""
+    Category = "conditioning"
+
+    def __call__(self, clip, text: str = "", mask=None, inverse_mask: bool = False, strength: float = 1.0, mode='default'):
+        return [_mask_text_encode(clip, text, mask, inverse_mask, strength, mode)]
+
+
 class CLIPTextEncode:
     """comfyUI/nodes.py:53-65"""
     RETURN_TYPES = ("CONDITIONING",)
@@ -67,8 +89,8 @@ class CLIPTextEncode:
 
 class SceneTextEncode(N.StableRenderingNode):
     """_nodes/conditions.py:78-160.  ``merge=True`` (what every shipped workflow uses): one positive and one negative prompt
-    concatenated from the sprites' and the environment's prompts.  ``merge=False`` without an IDMap: one conditioning per
-    prompt; with an IDMap the reference attaches per-sprite area masks, which the sampler here does not compose."""
+    concatenated from the sprites' and the environment's prompts.  ``merge=False``: one conditioning per prompt; with an IDMap
+    every sprite's prompts act only where the id map shows that sprite (masked conditioning, composed by the sampler)."""
     Category = "conditioning"
     N_OUTPUTS = 2
 
@@ -91,13 +113,22 @@ class SceneTextEncode(N.StableRenderingNode):
             conds.append(_text_encode(clip, pos))
             neg_conds.append(_text_encode(clip, neg))
             return conds, neg_conds
-        if idmap is not None:
-            raise NotImplementedError("SceneTextEncode(merge=False, idmap=...): per-sprite masked conditioning areas")
         for s in sprites:
             for text, w in ((getattr(s, "prompt", None), getattr(s, "prompt_weight", 1.0)),
                             (getattr(s, "neg_prompt", None), getattr(s, "neg_prompt_weight", 1.0))):
-                if text and w != 0:
-                    conds.append(_text_encode(clip, text, w))          # the reference appends both to `conds` (:128-133)
+                if not text or w == 0:
+                    continue
+                if idmap is None:
+                    # (the reference extends `conds` with the two halves of the pair here, conditions.py:124, and returns None
+                    #  for a weight != 1, :19-20: its sampler then fails; this keeps the evident intent -- one entry per prompt)
+                    conds.append(_text_encode(clip, text, w))
+                else:
+                    # per-sprite area: mask = pixels whose id map carries this sprite (first frame only: "not for baking",
+                    # conditions.py:80-91), prompt weight as the mask strength; BOTH prompts go to `conds` as in the reference
+                    t = idmap.tensor
+                    t = t[0] if t.dim() == 4 else t
+                    mask = (t[..., 0] == int(s.spriteID)).to(torch.float32).unsqueeze(0)
+                    conds.append(_mask_text_encode(clip, text, mask, strength=w))
         for e in envs:
             if getattr(e, "prompt", None) and getattr(e, "weight", 1.0) != 0:
                 conds.append(_text_encode(clip, e.prompt, e.weight))
@@ -286,7 +317,7 @@ class IfValTypeEqual(N.StableRenderingNode):
 
 for _name, _cls in (("CheckpointLoaderSimple", CheckpointLoaderSimple), ("LoraLoaderModelOnly", LoraLoaderModelOnly),
                     ("ControlNetLoader", ControlNetLoader), ("ControlNetApply", ControlNetApply), ("CLIPTextEncode", CLIPTextEncode),
-                    ("SceneTextEncode", SceneTextEncode), ("KSampler", KSampler), ("VAEDecode", VAEDecode),
+                    ("SceneTextEncode", SceneTextEncode), ("MaskedTextEncode", MaskedTextEncode), ("KSampler", KSampler), ("VAEDecode", VAEDecode),
                     ("IsNotNone", IsNotNone), ("If", If), ("IfValTypeEqual", IfValTypeEqual),
                     ("EngineData", N.EngineDataNode), ("VirtualEngineData", N.VirtualEngineDataNode),
                     ("InferenceOutput", N.InferenceOutputNode), ("EmptyCorrMaps", N.EmptyCorrMaps),

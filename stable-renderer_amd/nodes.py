@@ -43,24 +43,22 @@ def pooled_of(c):
     """the 'pooled_output' a CLIPTextEncode-style node left in the conditioning, or None"""
     if isinstance(c, torch.Tensor) or not c:
         return None
-    return c[0][1].get("pooled_output")
+    return c[0][1].get("pooled_output") if isinstance(c[0], (list, tuple)) else None
 
 
 def unwrap_conditioning(c):
     """CONDITIONING ([[cond, {..., 'control': AppliedControl}], ...], comfyUI/nodes.py:53-65, 806-848) or a bare
-    (1|N, 77, ctx) tensor -> (tensor, [AppliedControl, ...] newest first)"""
-    if isinstance(c, torch.Tensor):
-        return c, []
-    if len(c) != 1:
-        raise NotImplementedError(f"{len(c)} conditionings in one list (area / mask composition, comfy/samplers.py:90-206) "
-                                  "is not on the hot path; the shipped workflows produce one (SceneTextEncode merge=True)")
-    cond, extra = c[0]
-    if extra.get("mask") is not None or extra.get("area") is not None:
-        raise NotImplementedError("masked / area conditioning")
-    if float(extra.get("strength", 1.0)) != 1.0:
-        raise NotImplementedError("conditioning strength != 1 only acts through area composition")
-    ctl = extra.get("control")
-    return cond, (ctl.chain() if ctl is not None else [])
+    (1|N, 77, ctx) tensor -> (entries for DiffusionRunner.set_cond_entries, [AppliedControl, ...] newest first).  Several
+    entries / masks / strengths / areas are composed by the sampler as calc_cond_uncond_batch does (conditioning.py)."""
+    from .conditioning import entries_of
+    entries = entries_of(c)
+    if not entries:
+        raise ValueError("empty conditioning")
+    ctl = None
+    for e in entries:                                  # the batch's control is the last member's (samplers.py:258); the shipped
+        if e.get("control") is not None:               # graphs apply the same ControlNet chain to every entry of a list
+            ctl = e["control"]
+    return entries, (ctl.chain() if ctl is not None else [])
 
 
 class EngineDataNode(StableRenderingNode):
@@ -277,7 +275,7 @@ def custom_ksampler(model: MODEL, seed, steps, cfg, sampler_name, scheduler, pos
             net = cache[c.strength]
         nets.append(net)
     run = model.runner(N, h, w, cfg, controlnets=nets)
-    run.set_conditioning(positive, negative)
+    run.set_cond_entries(positive, negative)
     adm = model.cfg.get("adm_in_channels")
     if adm:                                            # SDXL family: y from the pooled text embedding + size embeddings
         from .sampling import encode_adm_sdxl

@@ -351,6 +351,25 @@ def cfg_denoise(x, eps, den, d, copies, sigma, cfg):
     L.check(L.lib().sr_cfg_denoise(_p(x), _p(eps), _p(den), _p(d), x.numel(), copies, float(sigma), float(cfg), stream_ptr()))
 
 
+def cond_crop_scale(x, xin, area, chunks, sigma):
+    """x (N,C,h,w) -> xin (chunks*N,C,ah,aw): the group's crop, EPS-scaled, once per chunk"""
+    N, Cc, h, w = x.shape
+    ah, aw, y0, x0 = area
+    L.check(L.lib().sr_cond_crop_scale(_p(x), _p(xin), N, Cc, h, w, ah, aw, y0, x0, chunks, float(sigma), stream_ptr()))
+
+
+def cond_accumulate(x, eps, mult, kinds, out_c, cnt_c, out_u, cnt_u, area, chunks, sigma):
+    N, Cc, h, w = x.shape
+    ah, aw, y0, x0 = area
+    L.check(L.lib().sr_cond_accumulate(_p(x), _p(eps), _p(mult), _p(kinds), _p(out_c), _p(cnt_c), _p(out_u), _p(cnt_u), N, Cc, h, w,
+                                       ah, aw, y0, x0, chunks, float(sigma), stream_ptr()))
+
+
+def cfg_combine(x, out_c, cnt_c, out_u, cnt_u, den, d, sigma, cfg):
+    L.check(L.lib().sr_cfg_combine(_p(x), _p(out_c), _p(cnt_c), _p(out_u), _p(cnt_u), _p(den), _p(d), x.numel(), float(sigma),
+                                   float(cfg), stream_ptr()))
+
+
 def euler_step(x, d, dt):
     L.check(L.lib().sr_euler_step(_p(x), _p(d), x.numel(), float(dt), stream_ptr()))
 

@@ -29,6 +29,24 @@ def broadcast(t, src, group=None):
     return t
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def broadcast_start(t, src, group=None):
+    """start a broadcast and return a handle whose ``wait()`` orders the CURRENT stream after the transfer.  RCCL: the
+    collective is enqueued on the process group's own stream (it first waits for the work already on the current stream), so
+    kernels launched on the current stream between this call and ``wait()`` overlap the transfer.  gloo (tests): staged and
+    synchronous."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return _Done()
+    if _staged(t) or not t.is_cuda:
+        broadcast(t, src, group)
+        return _Done()
+    return dist.broadcast(t, src=src, group=group, async_op=True)
+
+
 class ViewShard:
     def __init__(self, n_views, group=None):
         self.group = group

@@ -50,6 +50,36 @@ class BakeBallScene:
         ]
 
 
+class BoatScene:
+    """BASELINE config 3 (scripts/boat_example.py:84-103): a mesh loaded with ``Mesh.Load`` at the origin turning about Y
+    (AutoRotation; the headless driver fixes the pose per frame: ``deg_per_frame``), camera (0,3,-3) looking at the origin,
+    diffuse texture on the DefaultOpaqueMaterial.  The views are tied together the way the reference's bake scripts do it
+    (scripts/bake_ball.py:36-55, bake_example.py:52-70): a corr-map proxy sphere around the object -- k x k maps, texcoord
+    ids, BAKING mode, TRANSPARENT queue -- turning with it, so that the id / noise planes are anchored to the surface."""
+
+    def __init__(self, obj_path, W=512, H=512, k=6, seed=0, device="cuda", deg_per_frame=2.5, proxy_scale=1.5):
+        self.W, self.H, self.k = W, H, k
+        self.camera = S.Camera((0, 3, -3), (0, 0, 0), fov=45.0, near=0.1, far=100.0)
+        self.mesh = S.Mesh.Load(obj_path)
+        self.sphere = S.Mesh.Sphere(32)
+        g = torch.Generator().manual_seed(seed)
+        self.noise_tex = torch.randn(512, 512, 4, generator=g).half().to(device)
+        self.diffuse = torch.rand(64, 64, 4, generator=g).to(device)
+        self.diffuse[..., 3] = 1.0
+        self.corrmap = CorrespondMap(k=k, height=H, width=W, device=device)
+        self.sprite, self.material = 2, 2
+        self.deg_per_frame, self.proxy_scale = deg_per_frame, proxy_scale
+
+    def tasks(self, frame):
+        rot = S.rotate_y(self.deg_per_frame * float(frame))
+        return [
+            S.DrawTask(self.mesh, rot, sprite_id=1, material_id=1, render_mode=0, diffuse_tex=self.diffuse, order=999.8),
+            S.DrawTask(self.sphere, S.matmul(rot, S.scale(self.proxy_scale)), sprite_id=self.sprite, material_id=self.material,
+                       render_mode=2, corrmap_k=self.k, use_texcoord_id=True, id_size=(self.W, self.H), noise_tex=self.noise_tex,
+                       order=2000.2),
+        ]
+
+
 class CallOrder:
     """Tickets for the two sections of a call that touch process-wide state — the draws on the global CPU generator at the
     start of sampling and the frame-ordered ('first' priority) corr-map update — so that calls in flight on several streams
@@ -153,8 +183,8 @@ class FramePipeline:
         # ControlNetApply)
         self.controls = list(controls or [])
         self.shard = shard if (shard is not None and shard.world > 1) else None
-        if self.controls and self.shard is not None:
-            raise NotImplementedError("ControlNets with a view-sharded group")
+        # ControlNets inside a view-sharded group (BASELINE config 4): every rank runs the encoders on its OWN views' hints -- the
+        # reference calls the control model without a corresponder (controlnet.py:205-213), so there is no cross-view exchange in it
         self.N_all = n_views
         n_views = n_views if self.shard is None else self.shard.n_local
         self.N, self.steps, self.cfg, self.sampler, self.scheduler = n_views, steps, cfg, sampler, scheduler

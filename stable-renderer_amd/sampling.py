@@ -157,6 +157,8 @@ class DiffusionRunner:
         self.den = torch.empty_like(self.x)
         self.d = torch.empty_like(self.x)
         self._stream = torch.cuda.Stream(device=dev) if use_graph else None
+        self.time_comm, self._comm_events = False, []
+        self._entries, self._general = None, None
 
     def _ensure_plan(self, inject_idx):
         """the plan depends only on HOW MANY frames are injected; which ones is a device tensor rewritten per run"""
@@ -165,32 +167,7 @@ class DiffusionRunner:
         if self._plan is None or self._inject != key:
             control, inputs, cn = None, None, None
             if self.controlnets:
-                from .plan import PlanBuilder
-                B = self.N * self.copies
-                cfgu = self.unet.cfg
-                pb = PlanBuilder(self.unet.device, self.unet.dtype)
-                inputs = (pb.buf(B, cfgu["in_channels"], self.h, self.w, dtype=torch.float32, zero=True),
-                          pb.buf(B, dtype=torch.float32, zero=True), pb.buf(B, self.n_ctx, cfgu["context_dim"], zero=True))
-                cps = [c.build(B, self.h, self.w, *inputs, n_ctx=self.n_ctx) for c in self.controlnets]
-                outs, mid = list(cps[0]["output"]), cps[0]["middle"]
-                for cp in cps[1:]:                          # control_merge: element-wise sums of the residual lists
-                    merged = []
-                    for a, b in zip(outs, cp["output"]):
-                        if a is None or b is None:
-                            merged.append(a if b is None else b)
-                        else:
-                            y = pb.buf(*a.shape)
-                            pb.add(a, b, y)
-                            merged.append(y)
-                    outs = merged
-                    if mid is not None and cp["middle"] is not None:
-                        m2 = pb.buf(*mid.shape)
-                        pb.add(mid, cp["middle"], m2)
-                        mid = m2
-                    elif mid is None:
-                        mid = cp["middle"]
-                control = dict(output=outs, middle=mid)
-                cn = dict(plans=cps, merge=pb.take())
+                control, inputs, cn = self._build_controls(self.N * self.copies, self.h, self.w, self.n_ctx)
             self._plan = self.unet.build(self.N * self.copies, self.h, self.w, inject_idx=inject_idx, n_ctx=self.n_ctx,
                                          inject_external=sharded and inject_idx is not None, control=control, inputs=inputs)
             self._plan["cn"] = cn
@@ -203,6 +180,33 @@ class DiffusionRunner:
             self._plan["inject"].copy_(torch.tensor([int(i) for i in inject_idx], dtype=torch.int32))
         self._inject_global = inject_idx
         return self._plan
+
+    def _build_controls(self, B, h, w, n_ctx):
+        """ControlNet plans on shared (x, t, ctx) input buffers + the plan that sums their residuals (control_merge)"""
+        from .plan import PlanBuilder
+        cfgu = self.unet.cfg
+        pb = PlanBuilder(self.unet.device, self.unet.dtype)
+        inputs = (pb.buf(B, cfgu["in_channels"], h, w, dtype=torch.float32, zero=True),
+                  pb.buf(B, dtype=torch.float32, zero=True), pb.buf(B, n_ctx, cfgu["context_dim"], zero=True))
+        cps = [c.build(B, h, w, *inputs, n_ctx=n_ctx) for c in self.controlnets]
+        outs, mid = list(cps[0]["output"]), cps[0]["middle"]
+        for cp in cps[1:]:                          # control_merge: element-wise sums of the residual lists
+            merged = []
+            for a, b in zip(outs, cp["output"]):
+                if a is None or b is None:
+                    merged.append(a if b is None else b)
+                else:
+                    y = pb.buf(*a.shape)
+                    pb.add(a, b, y)
+                    merged.append(y)
+            outs = merged
+            if mid is not None and cp["middle"] is not None:
+                m2 = pb.buf(*mid.shape)
+                pb.add(mid, cp["middle"], m2)
+                mid = m2
+            elif mid is None:
+                mid = cp["middle"]
+        return dict(output=outs, middle=mid), inputs, dict(plans=cps, merge=pb.take())
 
     def set_control_hints(self, hints):
         """hints: one (N,3,8h,8w) tensor in [0,1] per ControlNet (ControlNetApply's image.movedim(-1,1), nodes.py:745-760);
@@ -221,6 +225,108 @@ class DiffusionRunner:
         """positive / negative: (1 | N, n_ctx, ctx_dim) text embeddings (CONDRegular.process_cond repeats a single
         embedding to the batch, comfy/conds.py:23-26).  Batch order = [uncond frames..., cond frames...]."""
         self._pos, self._neg = positive, negative
+        self._entries = None
+
+    def set_cond_entries(self, positive, negative):
+        """positive / negative: lists of conditioning entries (conditioning.entries_of): several prompts with masks, strengths
+        and areas, composed as calc_cond_uncond_batch does (comfy/samplers.py:176-320).  One plain entry each is the ordinary
+        [uncond | cond] batch."""
+        from . import conditioning as CD
+        if CD.is_plain(positive) and CD.is_plain(negative):
+            self._entries = None
+            return self.set_conditioning(positive[0]["cond"], negative[0]["cond"])
+        if self.shard is not None and self.shard.world > 1:
+            raise NotImplementedError("mask / area conditioning lists inside a view-sharded group")
+        self._entries = (list(positive), list(negative))
+        self._general = None
+
+    def _build_general(self, n_rand):
+        """group the entries into model calls and build one UNet plan per call shape (conditioning.groups_of)"""
+        from . import conditioning as CD
+        N, h, w = self.N, self.h, self.w
+        C = self.unet.cfg["in_channels"]
+        pos, neg = CD.prepare(self._entries[0], self._entries[1], h, w)
+        groups = CD.groups_of(pos, neg, N, C, h, w, use_uncond=self.copies == 2)
+        if n_rand is not None and len(groups) != 1:
+            raise NotImplementedError("K/V injection (OverlapCorresponder) with conditioning areas that need several model calls")
+        if self.controlnets and any(g["area"] != (h, w, 0, 0) for g in groups):
+            raise NotImplementedError("ControlNets with conditioning areas (the hint would need the same crop)")
+        dev = self.x.device
+        for g in groups:
+            ah, aw, _, _ = g["area"]
+            ch = len(g["members"])
+            g["chunks"] = ch
+            g["mult"] = torch.stack([m for _, _, m in g["members"]]).to(dev).contiguous()        # (chunks,N,C,ah,aw)
+            g["kinds"] = torch.tensor([k for k, _, _ in g["members"]], dtype=torch.int32, device=dev)
+            g["n_ctx"] = int(g["members"][0][1]["cond"].shape[1])
+        self._general = dict(groups=groups, built_for=None,
+                             out_c=torch.empty_like(self.x), cnt_c=torch.empty_like(self.x),
+                             out_u=torch.empty_like(self.x), cnt_u=torch.empty_like(self.x))
+        return self._general
+
+    def _general_plans(self, inject):
+        """build (once per injected-frame COUNT) and load the plans of the general path"""
+        G = self._general
+        key = None if inject is None else len(inject)
+        if G["built_for"] != ("built", key):
+            for g in G["groups"]:
+                ah, aw, _, _ = g["area"]
+                B = self.N * g["chunks"]
+                control, inputs, cn = None, None, None
+                if self.controlnets:
+                    control, inputs, cn = self._build_controls(B, ah, aw, g["n_ctx"])
+                g["plan"] = self.unet.build(B, ah, aw, inject_idx=inject, n_ctx=g["n_ctx"], control=control, inputs=inputs)
+                g["plan"]["cn"] = cn
+            G["built_for"] = ("built", key)
+        for g in G["groups"]:
+            p, N = g["plan"], self.N
+            if inject is not None:
+                B = N * g["chunks"]
+                if any(int(i) < 0 or int(i) >= B for i in inject):
+                    raise IndexError(f"injected frame index out of range: {list(inject)}")
+                p["inject"].copy_(torch.tensor([int(i) for i in inject], dtype=torch.int32))
+            dt = p["ctx"].dtype
+            for j, (_, e, _) in enumerate(g["members"]):
+                p["ctx"][j * N:(j + 1) * N].copy_(e["cond"].to(p["ctx"].device).to(dt).expand(N, -1, -1))
+            if p.get("y") is not None:
+                from .sampling import encode_adm_sdxl as _adm
+                adm = self.unet.cfg["adm_in_channels"]
+                for j, (_, e, _) in enumerate(g["members"]):
+                    if e.get("pooled_output") is None:
+                        raise ValueError("this model takes vector conditioning: a conditioning entry carries no 'pooled_output'")
+                    y = _adm(e["pooled_output"], width=self.w * 8, height=self.h * 8)
+                    p["y"][j * N:(j + 1) * N, :adm].copy_(y.to(p["y"].device).to(p["y"].dtype).expand(N, -1))
+            p["prologue"].run()
+            if p.get("cn") is not None:
+                if self._hints is None:
+                    raise ValueError("ControlNets are attached: call set_control_hints() before sampling")
+                for cp, hint in zip(p["cn"]["plans"], self._hints):
+                    hv = hint.to(cp["hint"].device, torch.float32)
+                    for j in range(g["chunks"]):
+                        cp["hint"][j * N:(j + 1) * N].copy_(hv.expand(N, -1, -1, -1) if hv.shape[0] == 1 else hv)
+                    cp["prologue"].run()
+        return G
+
+    def _general_denoise(self, sigma, timestep_index, want_d):
+        """one sampling_function call (samplers.py:323-358) over the prepared groups -> self.den (and self.d)"""
+        G = self._general
+        G["out_c"].zero_()
+        G["out_u"].zero_()
+        G["cnt_c"].fill_(1e-37)
+        G["cnt_u"].fill_(1e-37)
+        for g in G["groups"]:
+            p = g["plan"]
+            O.cond_crop_scale(self.x, p["x"], g["area"], g["chunks"], sigma)
+            p["t"].fill_(float(timestep_index))
+            if p.get("cn") is not None:
+                for cp in p["cn"]["plans"]:
+                    cp["step"].run()
+                p["cn"]["merge"].run()
+            p["step"].run()
+            O.cond_accumulate(self.x, p["out"], g["mult"], g["kinds"], G["out_c"], G["cnt_c"], G["out_u"], G["cnt_u"], g["area"],
+                              g["chunks"], sigma)
+        O.cfg_combine(self.x, G["out_c"], G["cnt_c"], G["out_u"], G["cnt_u"], self.den, self.d if want_d else None, sigma,
+                      self.cfg_scale)
 
     def _load_ctx(self, p):
         N = self.N
@@ -258,24 +364,12 @@ class DiffusionRunner:
         n = self.x.numel()
         O.eps_scale_input(self.x, p["x"], self.copies, sigma)
         p["t"].fill_(float(timestep_index))
-        if len(p["points"]) > 0:
-            # view-sharded group: the injected frame's post-LayerNorm tokens live on one rank; run the plan segment by
-            # segment and broadcast them over xGMI at each of the 16 cut points
-            from . import parallel as PAR
-            for si, seg in enumerate(p["segments"]):
-                seg.run()
-                if si < len(p["points"]):
-                    for ln, src in p["points"][si]:          # the rows and, with the folded LayerNorm, their statistics
-                        for j, g in enumerate(self._inject_global):
-                            owner, li = self.shard.owner_of(g)
-                            if owner == self.shard.rank:
-                                src[j].copy_(ln[li])
-                            PAR.broadcast(src[j], owner, self.shard.group)
-            return p["out"]
-        if p.get("cn") is not None:                         # ControlNet encoders on the same (x, t, ctx), then their merge
-            for cp in p["cn"]["plans"]:
+        if p.get("cn") is not None:                         # ControlNet encoders on the same (x, t, ctx), then their merge; no
+            for cp in p["cn"]["plans"]:                     # cross-view work inside them (controlnet.py:205-213 passes no corresponder)
                 cp["step"].run()
             p["cn"]["merge"].run()
+        if p["schedule"]:
+            return self._sharded_eval(p)
         if self.use_graph:
             if not self._captured:
                 torch.cuda.current_stream().synchronize()
@@ -286,6 +380,51 @@ class DiffusionRunner:
         else:
             p["step"].run()
         return p["out"]
+
+    def _sharded_eval(self, p):
+        """view-sharded group: the injected frame's post-LayerNorm tokens live on ONE rank.  The step plan is cut twice per
+        transformer block (BlockLowering.schedule): after norm1 the owner's rows go out over xGMI as an asynchronous RCCL
+        broadcast while every rank computes its own Q projection; the compute stream only waits for the rows before the K / V
+        projections.  Segments are replayed as hipGraphs when the runner uses graphs.  ``comm_ms`` (when
+        ``time_comm``) accumulates the time the compute stream spent stalled in those waits = the EXPOSED communication."""
+        from . import parallel as PAR
+        sched = p["schedule"]
+        if self.use_graph and not self._captured:
+            torch.cuda.current_stream().synchronize()
+            for kind, *rest in sched:                       # all captures up front: none while a collective is in flight
+                if kind == "run" and rest[0].n > 0:
+                    rest[0].capture(self._stream)
+            self._stream.synchronize()
+            self._captured = True
+        pending = []
+        for kind, *rest in sched:
+            if kind == "run":
+                rest[0].launch() if self.use_graph else rest[0].run()
+            elif kind == "bcast":
+                for ln, src in rest[0]:                      # the rows and, with the folded LayerNorm, their statistics
+                    for j, g in enumerate(self._inject_global):
+                        owner, li = self.shard.owner_of(g)
+                        if owner == self.shard.rank:
+                            src[j].copy_(ln[li])
+                        pending.append(PAR.broadcast_start(src[j], owner, self.shard.group))
+            else:                                            # "wait"
+                if self.time_comm:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                for h in pending:
+                    h.wait()
+                if self.time_comm:
+                    e1.record()
+                    self._comm_events.append((e0, e1))
+                pending = []
+        return p["out"]
+
+    def exposed_comm_ms(self):
+        """sum of the compute-stream stalls recorded since the last call (needs time_comm = True); synchronises"""
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._comm_events)
+        self._comm_events = []
+        return ms
 
     def sample(self, noise, steps, sampler_name, scheduler, denoise=1.0, latent_image=None, seed=None,
                inject_n_rand=None, step_callback=None, noise_fn=None, rng_turn=None):
@@ -308,10 +447,15 @@ class DiffusionRunner:
                 g = torch.manual_seed(seed + 1)
                 n_grp = noise.shape[0] if self.shard is None else self.shard.n_views     # the draw is over the WHOLE group
                 torch.randn((n_grp,) + tuple(noise.shape[1:]), generator=g, device="cpu")
+            general = getattr(self, "_entries", None) is not None
+            G = None
+            if general:
+                G = self._general if self._general is not None else self._build_general(
+                    inject_n_rand if (inject_n_rand is not None and inject_n_rand >= 0) else None)
             inject = None
             if inject_n_rand is not None and inject_n_rand >= 0:
                 n_all = self.N if self.shard is None else self.shard.n_views
-                B = n_all * self.copies
+                B = n_all * (G["groups"][0]["chunks"] if general else self.copies)
                 inject = torch.randint(1, B, (inject_n_rand,)).tolist()       # global RNG; B counts cond + uncond entries
                 if self.shard is not None and self.shard.world > 1:           # every rank must use rank 0's draw
                     from . import parallel as PAR
@@ -325,16 +469,23 @@ class DiffusionRunner:
         O.axpby(self.x, latent.to(dev, torch.float32).contiguous(), 1.0, s0)        # x = noise*s0 + latent
         if rng_turn is not None and sampler in ("ddpm", "lcm"):
             raise NotImplementedError("calls in flight draw per-step noise from the global generator with ddpm / lcm")
-        p = self._ensure_plan(inject)
-        self._load_ctx(p)
+        if general:
+            self._general_plans(inject)
+            p = G["groups"][0]["plan"]
+        else:
+            p = self._ensure_plan(inject)
+            self._load_ctx(p)
         if noise_fn is None:
             def noise_fn():
                 return torch.randn(tuple(self.x.shape), dtype=torch.float32).to(dev)    # default_noise_sampler (CPU x)
         t_index = [int(t) for t in self.ms.timestep(sig[:-1])]          # ModelSamplingDiscrete.timestep, once per run
         for i in range(len(sig) - 1):
             s, sn = float(sig[i]), float(sig[i + 1])
-            eps = self.model_eps(p, s, t_index[i])
-            O.cfg_denoise(self.x, eps, self.den, self.d if sampler in ("euler", "ddim") else None, self.copies, s, self.cfg_scale)
+            if general:
+                self._general_denoise(s, t_index[i], sampler in ("euler", "ddim"))
+            else:
+                eps = self.model_eps(p, s, t_index[i])
+                O.cfg_denoise(self.x, eps, self.den, self.d if sampler in ("euler", "ddim") else None, self.copies, s, self.cfg_scale)
             if step_callback is not None:
                 step_callback(SamplingCallbackContext(self.x, i, self.den, len(sig) - 1, ks.timesteps, sig.tolist()))
             if sampler in ("euler", "ddim"):

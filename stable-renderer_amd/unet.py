@@ -101,9 +101,13 @@ class BlockLowering:
         self.emb_s, self.ctx, self.n_ctx, self.inject_idx, self.sel = emb_s, ctx, n_ctx, inject_idx, sel
         self.ldt_ctx = _cdiv(n_ctx, 8) * 8
         # external=True (view-sharded multi-GPU): the injected frame's tokens come from another rank.  The plan is CUT
-        # after each norm1; ``segments`` are the plans between cuts and ``points`` the (ln, src) buffer pairs the host
-        # fills (owner: src <- ln[local index]) and broadcasts before launching the next segment.
-        self.external, self.segments, self.points = external, [], []
+        # twice per transformer block and ``schedule`` lists what the host does in order:
+        #   ("run", Plan)      ... up to and including norm1
+        #   ("bcast", pairs)   owner: src <- ln[local index]; START the broadcast of src (async on the RCCL stream)
+        #   ("run", Plan)      the B-frame Q projection: needs only the local ln, runs while the rows are on the wire
+        #   ("wait",)          the compute stream waits for the transfer
+        #   ("run", Plan)      K / V^T projections of the received rows, attention, ... next norm1
+        self.external, self.schedule = external, []
         # LayerNorm folded into its consumer GEMMs (pack_weights' ".f" tensors, sr_igemm_args.row_stats): parity-clean, but
         # measured neutral on the SD1.5 step (22.33 vs 22.27 ms: 0.81 ms of LayerNorm kernels become 0.25 ms of row statistics,
         # 0.1 ms of extra gathers and +0.3 ms of GEMM epilogue), so the explicit kernels stay the default; SR_FOLD_LN=1 enables
@@ -198,8 +202,12 @@ class BlockLowering:
             src = pb.buf(nr, HW, Cc)
             src_st = pb.buf(nr, HW, 2, dtype=torch.float32) if st1 is not None else None
             if self.external:
-                self.segments.append(pb.take())
-                self.points.append([(ln, src)] + ([(st1, src_st)] if st1 is not None else []))
+                self.schedule.append(("run", pb.take()))
+                self.schedule.append(("bcast", [(ln, src)] + ([(st1, src_st)] if st1 is not None else [])))
+                wq, kq = lin("attn1.to_q", st1)
+                pb.igemm(ln, wq, q, B * HW, 1, 1, Cc, Cc, **kq)
+                self.schedule.append(("run", pb.take()))
+                self.schedule.append(("wait",))
             # the injected frame's K / V^T are one-frame GEMMs (latency bound): side lane, beside the B-frame Q projection
             pb.fork()
             with pb.side():
@@ -211,8 +219,9 @@ class BlockLowering:
                 wv, kv = lin("attn1.to_v", src_st)
                 pb.igemm(src, wk, k, Tk, 1, 1, Cc, Cc, **kk)
                 pb.igemm(src, wv, vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt, **kv)
-            wq, kq = lin("attn1.to_q", st1)
-            pb.igemm(ln, wq, q, B * HW, 1, 1, Cc, Cc, **kq)
+            if not self.external:
+                wq, kq = lin("attn1.to_q", st1)
+                pb.igemm(ln, wq, q, B * HW, 1, 1, Cc, Cc, **kq)
             pb.join()
         a = pb.buf(B, HW, Cc)
         pb.attention(q, k, vt, a, B, Bk, HW, Tk, heads, d, ldt)
@@ -397,4 +406,4 @@ class UNet:
         flops = pb.flops
         step = pb.take()
         return dict(prologue=pro.take(), step=step, x=x_in, t=t_in, ctx=ctx, y=y_in, out=out, flops=flops, inject=sel, inject_err=sel_err,
-                    segments=low.segments + [step], points=low.points)
+                    schedule=(low.schedule + [("run", step)]) if low.schedule else [])

@@ -283,3 +283,82 @@ def test_sampling_with_an_sdxl_family_unet_needs_and_uses_vector_conditioning():
         out, _ = r.sample(noise, 2, "euler", "normal", seed=1)
         outs.append(out.clone())
     assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+
+
+def _cond_lists(ctx_dim, H, W):
+    """positive / negative conditioning LISTS in ComfyUI's format: strengths, a blob mask, a box mask turned into an area,
+    a percentage area"""
+    def c(seed):
+        return torch.randn(1, 77, ctx_dim, generator=torch.Generator().manual_seed(seed))
+    g = torch.Generator().manual_seed(5)
+    blob = torch.nn.functional.avg_pool2d(torch.randn(1, 1, H, W, generator=g).abs(), 31, 1, 15)[0]
+    blob = (blob > blob.median()).float()
+    box = torch.zeros(1, H, W)
+    box[:, H // 5: H * 3 // 4, W // 4: W * 4 // 5] = 1.0
+    return {
+        "masks_and_strengths": ([[c(1), {"strength": 1.3}], [c(2), {"mask": blob, "mask_strength": 0.7, "set_area_to_bounds": False}]],
+                                [[c(3), {}]], 6.0),
+        "areas": ([[c(4), {}], [c(5), {"area": ("percentage", 0.5, 0.5, 0.25, 0.25), "strength": 0.9}],
+                   [c(6), {"mask": box, "mask_strength": 1.0, "set_area_to_bounds": True}]], [[c(7), {}], [c(8), {"strength": 0.5}]], 4.0),
+        "cfg1": ([[c(9), {}], [c(10), {"mask": blob, "mask_strength": 1.0, "set_area_to_bounds": False}]], [[c(11), {}]], 1.0),
+    }
+
+
+@pytest.mark.parametrize("case", ["masks_and_strengths", "areas", "cfg1"])
+def test_conditioning_lists_with_masks_and_areas_vs_oracle(case):
+    """calc_cond_uncond_batch's composition on the HIP path (sr_cond_crop_scale / sr_cond_accumulate / sr_cfg_combine + one UNet
+    plan per model-call shape) against the oracle, whose composition arithmetic is pinned to the reference by the toy-model golden
+    (tests/test_oracle_golden.py::test_cond_composition_vs_reference)"""
+    import sr_oracle as ORC
+    from stable_renderer_amd.conditioning import entries_of
+    from stable_renderer_amd.sampling import DiffusionRunner
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    sd = _sd("unet_tiny_keys.json", 1)
+    net = UNet(sd, cfg, dtype=torch.float32)
+    N, h, w = 2, 16, 24
+    pos, neg, scale = _cond_lists(64, h * 8, w * 8)[case]
+    noise = torch.randn(N, 4, h, w, generator=torch.Generator().manual_seed(21))
+    run = DiffusionRunner(net, N, h, w, scale, n_ctx=77, use_graph=False)
+    run.set_cond_entries(entries_of(pos), entries_of(neg))
+    torch.manual_seed(3)
+    out, _ = run.sample(noise, 3, "euler", "normal")
+    torch.cuda.synchronize()
+    torch.manual_seed(3)
+    with torch.no_grad():
+        ref, _ = ORC.sample_frames(sd, cfg, noise, None, None, None, 3, scale, "euler", "normal",
+                                   cond_entries=(entries_of(pos), entries_of(neg)))
+    err = (out.cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < 2e-3, (case, err)
+    # the composition matters: the plain [neg | pos] run of the first entries gives a different latent
+    run.set_conditioning(pos[0][0], neg[0][0])
+    torch.manual_seed(3)
+    plain, _ = run.sample(noise, 3, "euler", "normal")
+    assert (plain.cpu() - ref).abs().max().item() > 1e-2
+
+
+def test_masked_text_nodes_feed_the_sampler():
+    """MaskedTextEncode / SceneTextEncode(merge=False, idmap) -> custom_ksampler: per-sprite prompts act through id-map masks"""
+    from stable_renderer_amd import graph_nodes as GN, nodes as N
+    from stable_renderer_amd.corrmap import IDMap
+    from stable_renderer_amd.types import Sprite, SpriteInfos, EnvPrompt, LATENT
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    model = N.MODEL(UNet(_sd("unet_tiny_keys.json", 1), cfg, dtype=torch.float32))
+    clip = GN.SyntheticCLIP(ctx_dim=64)
+    ids = torch.zeros(1, 128, 128, 4, dtype=torch.int32)
+    ids[:, 20:90, 10:70, 0] = 1
+    ids[:, 60:120, 60:125, 0] = 2
+    sprites = SpriteInfos({1: Sprite(1, "a red ball", 1.0, "blurry", 0.5), 2: Sprite(2, "a blue cube", 0.8)})
+    pos, neg = GN.SceneTextEncode()(clip, sprites, [EnvPrompt("studio light", "noise")], merge=False, idmap=IDMap(ids.cuda()))
+    assert len(pos) == 4 and len(neg) == 1                              # 3 sprite prompts (both signs, as the reference) + env
+    assert [("mask" in e[1]) for e in pos] == [True, True, True, False]
+    assert pos[1][1]["mask_strength"] == 0.5 and pos[2][1]["mask_strength"] == 0.8
+    assert float(pos[0][1]["mask"].sum()) == 70 * 60
+    one = GN.MaskedTextEncode()(clip, "a cat", mask=torch.ones(128, 128), inverse_mask=True, strength=0.3, mode="set_cond_area")
+    assert one[0][1]["set_area_to_bounds"] and float(one[0][1]["mask"].abs().sum()) == 0 and one[0][1]["mask"].dim() == 3
+    lat = LATENT(samples=torch.zeros(1, 4, 16, 16))
+    torch.manual_seed(0)
+    a = N.custom_ksampler(model, 5, 2, 4.0, "euler", "normal", pos, neg, lat)[0]["samples"]
+    b = N.custom_ksampler(model, 5, 2, 4.0, "euler", "normal", [pos[3]], neg, lat)[0]["samples"]
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() > 1e-3

@@ -161,3 +161,53 @@ def test_two_rank_pipeline_shard_bakes_the_same_corrmap():
         assert err < 2e-4, (rank, err)
         if rank == 0:
             assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same      # fp16 store of fp32 frames that differ by GEMM batch shape
+
+
+def _cn_worker(rank, world, port, q):
+    _guarded(_cn_body, rank, world, port, q)
+
+
+def _cn_body(rank, world):
+    """BASELINE config 4's composition: depth + normal ControlNets driven by the G-buffers INSIDE a view-sharded group,
+    2 ranks x 3 frames, OverlapCorresponder (latent all-gather per step, K/V-source broadcast per block)"""
+    from stable_renderer_amd.pipeline import build_sd15_pipeline
+    from stable_renderer_amd.parallel import ViewShard
+    from stable_renderer_amd.unet import SD15_CFG
+    torch.cuda.set_device(0)
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    kw = dict(dtype=torch.float32, n_views=6, steps=3, cfg=5.0, W=128, H=128, unet_cfg=cfg, use_graph=False, vae_ch=32,
+              controls=[("depth", 1.0), ("normal", 0.7)])
+
+    def run(shard, graph=False):
+        pipe = build_sd15_pipeline(shard=shard, **dict(kw, use_graph=graph))
+        torch.manual_seed(21)
+        imgs = pipe.call().clone()
+        torch.cuda.synchronize()
+        return pipe, imgs
+    p0, base = run(None)
+    sh = ViewShard(6)
+    assert sh.n_local == 3
+    p1, mine = run(sh)
+    err = (mine - base[sh.slice]).abs().max().item()
+    p2, mine_g = run(sh, graph=True)                    # the cut segments replayed as hipGraphs give the same frames
+    err_g = (mine_g - mine).abs().max().item()
+    # the ControlNets do change the result (a no-op control path would also "match")
+    pn = build_sd15_pipeline(shard=None, **dict(kw, controls=None))
+    torch.manual_seed(21)
+    plain = pn.call().clone()
+    moved = (plain - base).abs().max().item()
+    same = None
+    if rank == 0:
+        c0, c1 = p0.scene.corrmap, p1.scene.corrmap
+        same = (bool((c0._writtens == c1._writtens).all()), int(c0._writtens.sum()), (c0._values - c1._values).abs().max().item())
+    return (rank, err, err_g, moved, same)
+
+
+def test_two_ranks_three_frames_each_with_two_controlnets_match_single_process():
+    res = _run_ranks(_cn_worker, 2, 27700 + (os.getpid() % 1000), timeout=600)
+    for rank, err, err_g, moved, same in res:
+        assert err < 2e-4, (rank, err)
+        assert err_g < 1e-5, (rank, err_g)
+        assert moved > 1e-3, moved
+        if rank == 0:
+            assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same

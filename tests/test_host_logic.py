@@ -198,3 +198,28 @@ def test_latent_scale_follows_the_model_family():
     assert torch.equal(lat * latent_scale_of(SDXL_CFG), torch.from_numpy(d["sdxl_in"]))
     assert torch.equal(lat * latent_scale_of(SD15_CFG), torch.from_numpy(d["sd15_in"]))
     assert torch.allclose(lat / latent_scale_of(SDXL_CFG), torch.from_numpy(d["sdxl_out"]), rtol=1e-6)
+
+
+def test_conditioning_list_preparation_matches_the_reference():
+    """conditioning.prepare / groups_of (host side of calc_cond_uncond_batch): resolved areas, opposite-area entries and the
+    batch composition of every model call equal what the reference's samplers.sample() + calc_cond_uncond_batch did (golden
+    cond_compose.npz); the weights tensors equal the oracle's get_area_and_mult restatement"""
+    import sr_oracle as ORC
+    from stable_renderer_amd import conditioning as CD
+    from test_oracle_golden import load_cond_case
+    d = np.load(os.path.join(GOLD, "cond_compose.npz"))
+    meta = json.loads(bytes(d["meta"]).decode())
+    x = torch.from_numpy(d["x"])
+    for name, m in meta.items():
+        pos, neg = load_cond_case(d, meta, name)
+        p, n = CD.prepare(pos, neg, 16, 24)
+        assert [None if e.get("area") is None else list(e["area"]) for e in p] == m["areas_pos"], name
+        assert [None if e.get("area") is None else list(e["area"]) for e in n] == m["areas_neg"], name
+        groups = CD.groups_of(p, n, 2, 4, 16, 24)
+        assert [[k for k, _, _ in g["members"]] for g in groups] == [cl[1] for cl in m["calls"]], name
+        assert [[2 * len(g["members"]), 4, g["area"][0], g["area"][1]] for g in groups] == [cl[0] for cl in m["calls"]], name
+        for e in p + n:
+            assert torch.equal(CD.mult_of(e, 2, 4, 16, 24)[0], ORC.area_and_mult(e, x)[1]), name
+    assert CD.is_plain(CD.entries_of(torch.zeros(1, 77, 8))) and not CD.is_plain(CD.entries_of([[torch.zeros(1, 77, 8), {"strength": 0.5}]]))
+    with pytest.raises(TypeError):
+        CD.entries_of([torch.zeros(1, 77, 8), {}])           # the flattened pair SceneTextEncode(merge=False, idmap=None) builds in the reference

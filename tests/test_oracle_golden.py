@@ -215,3 +215,44 @@ def test_legacy_overlap(gold):
             assert np.allclose(o2, d[f"resize_{algo}_r{r}"], atol=2e-5, rtol=1e-5), (algo, r)
         # radius 0 is order independent: the parallel (Jacobi) form is identical
         assert np.allclose(O.legacy_overlap(frames, ids, 0.6, 0, algo, vn, sequential=False), d[f"full_{algo}_r0"], atol=2e-5)
+
+
+def load_cond_case(d, meta, name):
+    """-> (pos entries, neg entries) in the oracle's / product's entry format from the cond_compose golden"""
+    out = {}
+    for kind in ("pos", "neg"):
+        lst = []
+        for i, ex in enumerate(meta[name]["entries"][kind]):
+            e = {k: (tuple(v) if isinstance(v, list) else v) for k, v in ex.items() if k != "has_mask"}
+            e["cond"] = T(d[f"{name}_{kind}{i}_c"])
+            if ex.get("has_mask"):
+                e["mask"] = T(d[f"{name}_{kind}{i}_mask"])
+            lst.append(e)
+        out[kind] = lst
+    return out["pos"], out["neg"]
+
+
+def toy_model(xin, sg, ctx):
+    b = xin.shape[0]
+    return (xin * 0.5 + ctx.mean(dim=(1, 2)).view(-1, 1, 1, 1) + 0.01 * sg.view(-1, 1, 1, 1)
+            + 0.001 * torch.arange(b, dtype=torch.float32).view(-1, 1, 1, 1))
+
+
+def test_cond_composition_vs_reference(gold):
+    """masks / strengths / areas / opposite-area entries / batching order / CFG: the oracle's restatement against the reference's
+    calc_cond_uncond_batch + sampling_function driven by the same toy model (golden cond_compose.npz)"""
+    d = gold("cond_compose")
+    meta = meta_of(d)
+    x, sigma = T(d["x"]), T(d["sigma"])
+    for name, m in meta.items():
+        pos, neg = load_cond_case(d, meta, name)
+        p, n = O.prepare_cond_entries(pos, neg, 16, 24)
+        assert len(p) == m["n_pos"] and len(n) == m["n_neg"], name
+        assert [None if e.get("area") is None else list(e["area"]) for e in p] == m["areas_pos"], name
+        assert [None if e.get("area") is None else list(e["area"]) for e in n] == m["areas_neg"], name
+        c, u, batches = O.calc_cond_uncond_batch(toy_model, p, n, x, sigma)
+        assert [[1 if k == "neg" else 0 for k, _ in b] for b in batches] == [cl[1] for cl in m["calls"]], name
+        assert torch.allclose(c, T(d[f"{name}_cond"]), atol=1e-6, rtol=1e-6), name
+        assert torch.allclose(u, T(d[f"{name}_uncond"]), atol=1e-6, rtol=1e-6), name
+        r = O.sampling_function(toy_model, x, sigma, n, p, m["scale"])
+        assert torch.allclose(r, T(d[f"{name}_cfg"]), atol=1e-5, rtol=1e-6), name
