@@ -84,6 +84,12 @@ typedef struct {
                              workgroups per CU for the K-short linear layers), 11 = 128x128 as 8 waves and 12 = 256x128 with 64-byte K-steps
                              (fp16; the same for widths that are multiples of 128 only).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
   int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split                      */
+  int32_t pad_br;         /* 1: a 3x3 conv pads ONLY the bottom / right border (window of output (y,x) starts at input
+                             (y*stride, x*stride)): the VAE encoder's Downsample = F.pad(x, (0,1,0,1)) + conv(stride 2,
+                             padding 0) (comfy/ldm/modules/diffusionmodules/model.py:77-95).  0: symmetric KH/2 padding          */
+  int32_t up_h, up_w;     /* with upsample = 1: output size of the fused nearest upsample when it is not exactly 2H x 2W (0 = x2);
+                             src = floor(dst * in/out) as F.interpolate(mode="nearest"): odd-sized latents (conditioning areas)
+                             where Upsample.forward targets the skip tensor's size (openaimodel.py:109-121)                      */
 } sr_igemm_args;
 int sr_igemm(const sr_igemm_args* args, void* stream);
 
@@ -201,6 +207,10 @@ int sr_cond_accumulate(const float* x, const float* eps, const float* mult, cons
 int sr_cfg_combine(const float* x, const float* out_c, const float* cnt_c, const float* out_u, const float* cnt_u, float* denoised,
                    float* d, int64_t n, float sigma, float cfg, void* stream);
 int sr_euler_step(float* x, const float* d, int64_t n, float dt, void* stream);           /* x += d*dt */
+/* VAE.encode's posterior sample (comfy/ldm/modules/distributions/distributions.py:24-37 via DiagonalGaussianRegularizer,
+ * comfy/ldm/models/autoencoder.py:13-31): moments (B, HW, 2*zc) fp32 NHWC = [mean | logvar] from quant_conv;
+ * z[b,c,p] = mean + exp(0.5*clamp(logvar,-30,20)) * noise[b,c,p]; noise / z (B, zc, HW) fp32 NCHW */
+int sr_vae_sample(const float* moments, const float* noise, float* z, int32_t B, int32_t zc, int32_t HW, void* stream);
 /* DDPMSampler_step + rescale; noise = host-drawn randn (may be NULL when sigma_next == 0) */
 int sr_ddpm_step(float* x, const float* denoised, const float* noise, int64_t n, float sigma, float sigma_next,
                  void* stream);

@@ -382,7 +382,11 @@ def sec_unet():
         oc._random_frame_indices = torch.tensor([2])
         y_inj = m(x, t, context=ctx, transformer_options={"positive_cond_indices": [2, 3]},
                   engine_data=object(), corresponder=oc)
-        save("unet_tiny", x=x, t=t, ctx=ctx, y=y, y_inj=y_inj, inj_idx=oc._random_frame_indices)
+        # a latent whose sizes do not halve evenly (what a conditioning AREA crops out): 10x12 -> 5x6 -> 3x3 -> 2x2; the decoder's
+        # Upsample then interpolates to the skip tensor's size instead of x2 (openaimodel.py:100-117)
+        x_odd = rnd(9, 2, 4, 10, 12)
+        y_odd = m(x_odd, t[:2], context=ctx[:2], transformer_options={})
+        save("unet_tiny", x=x, t=t, ctx=ctx, y=y, y_inj=y_inj, inj_idx=oc._random_frame_indices, x_odd=x_odd, y_odd=y_odd)
         del m
         # real SD1.5 shapes, 16x16 latent, B=2
         m, ns, norm = build_unet(SD15, seed=0)
@@ -452,6 +456,34 @@ def sec_vae():
         # Decoder + clamp((y+1)/2) + NHWC
         img = torch.clamp((y + 1.0) / 2.0, min=0.0, max=1.0).movedim(1, -1)
         save("vae_dec", z=z, y=y, img=img)
+
+
+def sec_vaeenc():
+    """VAE.encode's arithmetic from the reference classes: Encoder (model.py:441-520) + AutoencoderKL.quant_conv +
+    DiagonalGaussianRegularizer(sample=True) (autoencoder.py:13-31, 175-190), full SD1.x width, 64x64 pixels"""
+    from comfy.ldm.models.autoencoder import AutoencoderKL
+    dd = {'double_z': True, 'z_channels': 4, 'resolution': 256, 'in_channels': 3, 'out_ch': 3, 'ch': 128,
+          'ch_mult': [1, 2, 4, 4], 'num_res_blocks': 2, 'attn_resolutions': [], 'dropout': 0.0}
+    with torch.no_grad():
+        ae = AutoencoderKL(ddconfig=dd, embed_dim=4)
+        ae.eval()
+
+        class Enc(torch.nn.Module):                 # state-dict order = Encoder names, then quant_conv
+            def __init__(self):
+                super().__init__()
+                for n, m in ae.encoder.named_children():
+                    setattr(self, n, m)
+                self.quant_conv = ae.quant_conv
+        ns, norm = synth.fill_module_(Enc(), seed=3)
+        _jdump({"names_shapes": ns, "norm_names": norm}, os.path.join(GOLD, "vae_enc_keys.json"))
+        pixels = torch.rand(2, 64, 64, 3, generator=torch.Generator().manual_seed(9))
+        x = pixels.movedim(-1, 1) * 2.0 - 1.0       # VAE.process_input (sd.py:222)
+        mom = ae.quant_conv(ae.encoder(x))
+        torch.manual_seed(31)
+        z = ae.encode(x)                            # draws torch.randn(mean.shape) from the global generator
+        torch.manual_seed(31)
+        noise = torch.randn(2, 4, 8, 8)
+        save("vae_enc", pixels=pixels, moments=mom, z=z, noise=noise)
 
 
 def sec_e2e():
@@ -855,7 +887,7 @@ def sec_workflow():
 
 SECTIONS = dict(math=sec_math, idmap=sec_idmap, overlap=sec_overlap, corrmap=sec_corrmap, noisepool=sec_noisepool,
                 sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet, legacy=sec_legacy,
-                gbufdump=sec_gbufdump, workflow=sec_workflow, sdxl=sec_sdxl, conds=sec_conds)
+                gbufdump=sec_gbufdump, workflow=sec_workflow, sdxl=sec_sdxl, conds=sec_conds, vaeenc=sec_vaeenc)
 
 if __name__ == "__main__":
     todo = _ARGV or list(SECTIONS)

@@ -400,7 +400,9 @@ def unet_forward(sd, cfg, x, t, ctx, inject_idx=None, control=None):
                 h = _stransformer(sd, f"output_blocks.{bi}.1", h, ctx, heads, depth, inject_idx)
                 j = 2
             if lev > 0 and i == cfg["num_res_blocks"][lev]:
-                h = F.interpolate(h, scale_factor=2, mode="nearest")
+                # Upsample.forward(x, output_shape = hs[-1].shape) (openaimodel.py:100-117, :59-60): x2 unless a size was odd
+                size = (hs[-1].shape[2], hs[-1].shape[3]) if hs else (h.shape[2] * 2, h.shape[3] * 2)
+                h = F.interpolate(h, size=size, mode="nearest")
                 h = F.conv2d(h, sd[f"output_blocks.{bi}.{j}.conv.weight"], sd[f"output_blocks.{bi}.{j}.conv.bias"], padding=1)
             bi += 1
     h = F.silu(_gn(h, sd, "out.0", 1e-5))
@@ -440,6 +442,33 @@ def vae_decoder(sd, z, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
             h = F.conv2d(h, sd[f"up.{lev}.upsample.conv.weight"], sd[f"up.{lev}.upsample.conv.bias"], padding=1)
     h = F.silu(_gn(h, sd, "norm_out", 1e-6))
     return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
+def vae_encoder_moments(sd, x, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    """Encoder.forward (model.py:500-520) + quant_conv (autoencoder.py:175-181): x (B,3,H,W) in [-1,1] -> (B,2z,h,w)"""
+    h = F.conv2d(x, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    for lev in range(len(ch_mult)):
+        for i in range(num_res_blocks):
+            h = _vae_res(sd, f"down.{lev}.block.{i}", h)
+        if lev != len(ch_mult) - 1:                                    # Downsample (:88-92): pad bottom/right, stride-2 conv
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1), mode="constant", value=0), sd[f"down.{lev}.downsample.conv.weight"],
+                         sd[f"down.{lev}.downsample.conv.bias"], stride=2)
+    h = _vae_res(sd, "mid.block_1", h)
+    h = _vae_attn(sd, "mid.attn_1", h)
+    h = _vae_res(sd, "mid.block_2", h)
+    h = F.conv2d(F.silu(_gn(h, sd, "norm_out", 1e-6)), sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+    return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+
+
+def vae_encode(sd, pixels, noise=None, **kw):
+    """VAE.encode (sd.py:353-371): pixels (B,H,W,3) in [0,1]; posterior sample mean + std*randn (distributions.py:24-37),
+    noise drawn from the global generator when not given"""
+    mom = vae_encoder_moments(sd, pixels[..., :3].movedim(-1, 1) * 2.0 - 1.0, **kw)
+    mean, logvar = torch.chunk(mom, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    if noise is None:
+        noise = torch.randn(mean.shape)
+    return mean + std * noise
 
 
 def vae_decode_image(sd, z, **kw):                          # comfy/sd.py:329-346 (Decoder part)

@@ -5,6 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsr_hip.so")
+_DEV_LIB = os.environ.get("SR_DEV_LIB")          # development only: an experimental build of the library (tools/); no hash check
 
 SR_F16, SR_F32 = 0, 1
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_TIMESTEP_EMBED, OP_SILU,
@@ -21,7 +22,7 @@ class IgemmArgs(C.Structure):
                 ("zero_page", vp), ("B", i32), ("H", i32), ("W", i32), ("C1", i32), ("C2", i32), ("N", i32),
                 ("KH", i32), ("stride", i32), ("upsample", i32), ("act", i32), ("transpose_out", i32), ("ldt", i32),
                 ("out_f32", i32), ("dtype", i32), ("scale", f32), ("rowvec_ld", i32), ("workspace", vp),
-                ("workspace_bytes", C.c_int64), ("row_stats", vp), ("colsum", vp), ("tile", i32), ("split", i32)]
+                ("workspace_bytes", C.c_int64), ("row_stats", vp), ("colsum", vp), ("tile", i32), ("split", i32), ("pad_br", i32), ("up_h", i32), ("up_w", i32)]
 
 
 class GroupNormArgs(C.Structure):
@@ -114,6 +115,7 @@ SYMBOLS = {
     "sr_cond_accumulate": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "sr_cfg_combine": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, vp]),
     "sr_euler_step": (C.c_int, [vp, vp, i64, f32, vp]),
+    "sr_vae_sample": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "sr_ddpm_step": (C.c_int, [vp, vp, vp, i64, f32, f32, vp]),
     "sr_lcm_step": (C.c_int, [vp, vp, vp, i64, f32, vp]),
     "sr_axpby": (C.c_int, [vp, vp, i64, f32, f32, vp]),
@@ -160,6 +162,13 @@ def lib():
     (sr_source_hash() == hash of csrc/*.hip, headers, build flags): a missing or stale library is rebuilt when hipcc is there
     and refused otherwise -- it is never loaded silently (a stale .so was tested once: commit e818dd3)."""
     global _lib
+    if _lib is None and _DEV_LIB:
+        L = C.CDLL(_DEV_LIB)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
     if _lib is None:
         bm = _build_module()
         want = bm.source_hash()

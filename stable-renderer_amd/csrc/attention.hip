@@ -312,13 +312,25 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
 // S lives in two register sets that swap roles every tile (loop unrolled by two); K/V tiles go through a 3-slot LDS ring
 // (tile t+2 is written while t and t+1 are read) with ONE barrier per tile; global loads run one more tile ahead in
 // registers.  The interleave itself is requested with sched_group_barrier (1 MFMA : n VALU).
-template <int DQ, int DT, bool SR, int MB, int NTHR = 256>
+// LAZY (default): the softmax shift rides inside the QK^T product and is only moved when it has to be.
+//   * Q is pre-scaled by scale*log2(e) once (fp16), channel d of every staged K row is 1.0 and channel d of the Q fragment holds
+//     -m (the running shift, kept fp16-representable so the MFMA sees exactly the value the bookkeeping uses): the MFMA delivers
+//     S' = log2-scaled score - m and the per-score fused multiply-subtract disappears from the VALU-bound loop;
+//   * m follows the row maximum lazily: it is moved (O rescaled, the pending S' tile shifted, the fragment rewritten) only when a
+//     tile's maximum exceeds the current shift by more than 2^TAU -- probabilities stay <= 256, comfortably inside fp16 / fp32
+//     accumulation -- and always after the first tile; softmax is shift invariant, so only rounding differs from the exact-max form;
+//   * the two cross-row max reductions are v_permlane16_swap / v_permlane32_swap (VALU) instead of ds_bpermute round trips.
+#ifndef SR_ATTN_DBG
+#define SR_ATTN_DBG 0        // development only: 1 = no per-tile barrier / loads (timing of the compute alone; wrong results),
+#endif                       // 2 = exp replaced by a multiply, 3 = both
+template <int DQ, int DT, bool SR, int MB, int NTHR = 256, bool LAZY = false, int KTB = 4, int QT = 2>
 __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_args p) {
   using T = _Float16;
-  constexpr int EPC = 8, QT = 2;
-  constexpr int NCH = 4 * DQ, KROW = NCH * 16, VROW = KV_TILE * 2 + 8, VCH = KV_TILE * 2 / 16;
-  constexpr int K_BYTES = KV_TILE * KROW, V_BYTES = DT * 16 * VROW, TILE_B = K_BYTES + V_BYTES;
-  constexpr int KPT = (KV_TILE * NCH + NTHR - 1) / NTHR, VPT = (DT * 16 * VCH + NTHR - 1) / NTHR;
+  constexpr int EPC = 8;
+  constexpr int KV = 16 * KTB;                               // keys per tile: 64 (KTB 4) or 32 (KTB 2: half the S registers)
+  constexpr int NCH = 4 * DQ, KROW = NCH * 16, VROW = KV * 2 + 8, VCH = KV * 2 / 16;
+  constexpr int K_BYTES = KV * KROW, V_BYTES = DT * 16 * VROW, TILE_B = K_BYTES + V_BYTES;
+  constexpr int KPT = (KV * NCH + NTHR - 1) / NTHR, VPT = (DT * 16 * VCH + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   const int bk = p.Bk == 1 ? 0 : b;
   const int d = p.d, Tk = p.Tk;
   const int q0 = blockIdx.x * ((NTHR / 64) * 16 * QT) + wv * (16 * QT);
-  const int NT = (Tk + KV_TILE - 1) / KV_TILE;
+  const int NT = (Tk + KV - 1) / KV;
 
   uint4 qf[QT][DQ];
 #pragma unroll
@@ -348,19 +360,35 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
     for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float mrow[QT], lrow[QT], alpha[QT];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) { mrow[qt] = -INFINITY; lrow[qt] = 0.f; alpha[qt] = 1.f; }
+  for (int qt = 0; qt < QT; ++qt) { mrow[qt] = LAZY ? 0.f : -INFINITY; lrow[qt] = 0.f; alpha[qt] = 1.f; }
   const float sl2 = p.scale * 1.4426950408889634f;
+  // LAZY: where channel d sits in the Q fragment (d is a multiple of 8 and < 32*DQ: st = d/32, lane group (d%32)/8, element 0)
+  const int m_st = d >> 5, m_g4 = (d & 31) >> 3;
+  float delta[QT];                                           // pending move of the shift (0 = none)
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) delta[qt] = 0.f;
+  bool first_tile = true;
+  constexpr float TAU = 8.0f;
+  if constexpr (LAZY) {
+    const _Float16 hs = (_Float16)sl2;
+    const h16x8 hsv = {hs, hs, hs, hs, hs, hs, hs, hs};
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int st = 0; st < DQ; ++st) qf[qt][st] = __builtin_bit_cast(uint4, __builtin_bit_cast(h16x8, qf[qt][st]) * hsv);
+  }
 
   // ---- per-thread load slots (loop invariant): which K / V^T chunk this thread moves every tile
   const T* kbase = (const T*)p.k + (int64_t)bk * Tk * p.k_stride + h * d;
   const T* vbase = (const T*)p.vt + ((int64_t)bk * p.heads + h) * (int64_t)d * p.ldt;
-  int k_key[KPT], k_lds[KPT], k_el[KPT]; bool k_ok[KPT];
+  int k_key[KPT], k_lds[KPT], k_el[KPT]; bool k_ok[KPT], k_one[KPT];
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
     const int idx = tid + i * NTHR, key = idx / NCH, ch = idx - key * NCH;
     k_key[i] = key; k_el[i] = ch * EPC;
-    k_ok[i] = idx < KV_TILE * NCH && ch * EPC < d;
-    k_lds[i] = idx < KV_TILE * NCH ? key * KROW + ((NCH == 8) ? (ch ^ (key & 7)) : ch) * 16 : -1;
+    k_one[i] = LAZY && idx < KV * NCH && ch * EPC == d;     // the shift channel: 1.0 in element 0
+    k_ok[i] = idx < KV * NCH && ch * EPC < d;
+    k_lds[i] = idx < KV * NCH ? key * KROW + ((NCH == 8) ? (ch ^ (key & 7)) : ch) * 16 : -1;
   }
   const T* v_src[VPT]; int v_lds[VPT], v_k8[VPT]; bool v_ok[VPT], v_one[VPT];
 #pragma unroll
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int key = min(k0 + k_key[i], Tk - 1);            // rows past Tk: any valid row, their scores are masked to -inf
-      rk[i] = make_uint4(0, 0, 0, 0);
+      rk[i] = k_one[i] ? make_uint4(0x00003C00u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
       if (k_ok[i]) rk[i] = *(const uint4*)(kbase + (int64_t)key * p.k_stride + k_el[i]);
     }
 #pragma unroll
@@ -396,68 +424,91 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   };
 
   // ---- pipeline pieces
-  auto qk = [&](f32x4 (&s)[4][QT], int slot) {
+  auto qk = [&](f32x4 (&s)[KTB][QT], int slot) {
     const char* cK = smem + slot * TILE_B;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < KTB; ++kt)
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int st = 0; st < DQ; ++st) {
-      uint4 kf[4];
+      uint4 kf[KTB];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
+      for (int kt = 0; kt < KTB; ++kt) {
         const int key = kt * 16 + c16, ch = 4 * st + g4;
         kf[kt] = *(const uint4*)(cK + key * KROW + ((NCH == 8) ? (ch ^ (key & 7)) : ch) * 16);
       }
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < KTB; ++kt)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) sr_mma(s[kt][qt], kf[kt], qf[qt][st], T());
     }
   };
+  // max over the 4 lanes (g4 = 0..3) that hold one query: two permlane swaps + two max (VALU only)
+  auto max_over_g4 = [&](float x) -> float {
+    if constexpr (LAZY) {
+      auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+      auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+    } else {
+      x = fmaxf(x, __shfl_xor(x, 16));
+      return fmaxf(x, __shfl_xor(x, 32));
+    }
+  };
   // row max of a fresh S tile -> running max, alpha (applied to O and l at the start of the next iteration)
-  auto rowmax = [&](f32x4 (&s)[4][QT], int k0, bool mask) {
+  auto rowmax = [&](f32x4 (&s)[KTB][QT], int k0, bool mask) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       if (mask) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < KTB; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (k0 + kt * 16 + 4 * g4 + r >= Tk) s[kt][qt][r] = -INFINITY;
       }
       float mx = -INFINITY;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < KTB; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mnew = fmaxf(mrow[qt], mx * sl2);
-      alpha[qt] = __builtin_amdgcn_exp2f(mrow[qt] - mnew);
-      mrow[qt] = mnew;
+      mx = max_over_g4(mx);
+      if constexpr (LAZY) {
+        // s already is (log2 score - m): move m only if this tile tops it by more than TAU (always after the first tile)
+        float dl = 0.f;
+        if (first_tile || mx > TAU) {
+          const float mnew = (float)(_Float16)(mrow[qt] + mx);     // keep the shift fp16 representable
+          dl = mnew - mrow[qt];
+          mrow[qt] = mnew;
+        }
+        delta[qt] = dl;
+      } else {
+        const float mnew = fmaxf(mrow[qt], mx * sl2);
+        alpha[qt] = __builtin_amdgcn_exp2f(mrow[qt] - mnew);
+        mrow[qt] = mnew;
+      }
     }
+    first_tile = false;
   };
   // P = exp2(S*c - m) packed to the fp16 B-operand layout of the PV product
-  auto expo = [&](f32x4 (&s)[4][QT], uint4 (&pf)[2][QT]) {
+  auto expo = [&](f32x4 (&s)[KTB][QT], uint4 (&pf)[KTB / 2][QT]) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const f32x2 sl2v = {sl2, sl2}, nmv = {-mrow[qt], -mrow[qt]};
       float ps = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < KTB; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           f32x2 t = {s[kt][qt][r], s[kt][qt][r + 1]};
-          t = __builtin_elementwise_fma(t, sl2v, nmv);
-          const float e0 = __builtin_amdgcn_exp2f(t[0]), e1 = __builtin_amdgcn_exp2f(t[1]);
+          if constexpr (!LAZY) t = __builtin_elementwise_fma(t, sl2v, nmv);
+          const float e0 = (SR_ATTN_DBG & 2) ? t[0] * 0.001f : __builtin_amdgcn_exp2f(t[0]), e1 = (SR_ATTN_DBG & 2) ? t[1] * 0.001f : __builtin_amdgcn_exp2f(t[1]);
           s[kt][qt][r] = e0; s[kt][qt][r + 1] = e1;
           if constexpr (!SR) ps += e0 + e1;
         }
       if constexpr (!SR) lrow[qt] += ps;
 #pragma unroll
-      for (int kp = 0; kp < 2; ++kp) {
+      for (int kp = 0; kp < KTB / 2; ++kp) {
         h16x8 hv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { hv[r] = (_Float16)s[2 * kp][qt][r]; hv[4 + r] = (_Float16)s[2 * kp + 1][qt][r]; }
@@ -473,10 +524,10 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
       for (int dt = 0; dt < DT; ++dt) { o[dt][qt][0] *= alpha[qt]; o[dt][qt][1] *= alpha[qt]; o[dt][qt][2] *= alpha[qt]; o[dt][qt][3] *= alpha[qt]; }
     }
   };
-  auto pv = [&](const uint4 (&pf)[2][QT], int slot) {
+  auto pv = [&](const uint4 (&pf)[KTB / 2][QT], int slot) {
     const char* cV = smem + slot * TILE_B + K_BYTES;
 #pragma unroll
-    for (int kp = 0; kp < 2; ++kp) {
+    for (int kp = 0; kp < KTB / 2; ++kp) {
       uint4 vf[DT];                                          // one burst of V^T fragment reads per key half, then the MFMAs
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -495,43 +546,67 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
 
   // ---- prologue: tiles 0..2 into the ring, tile 3 in registers, S(0) and its row max
   gload(0); lstore(0);
-  if (NT > 1) { gload(KV_TILE); lstore(1); }
-  if (NT > 2) { gload(2 * KV_TILE); lstore(2); }
-  if (NT > 3) gload(3 * KV_TILE);
+  if (NT > 1) { gload(KV); lstore(1); }
+  if (NT > 2) { gload(2 * KV); lstore(2); }
+  if (NT > 3) gload(3 * KV);
   __syncthreads();
-  f32x4 sA[4][QT], sB[4][QT];
+  f32x4 sA[KTB][QT], sB[KTB][QT];
   qk(sA, 0);
   rowmax(sA, 0, NT == 1);
 
   int slot = 0;                                              // ring slot of tile t
   // STEADY: tile t+1 exists and is a full tile (compile-time straight-line body); otherwise wave-uniform run-time flags
-  auto iter = [&](f32x4 (&sc)[4][QT], f32x4 (&sn)[4][QT], int t, auto steady_tag) {
+  auto iter = [&](f32x4 (&sc)[KTB][QT], f32x4 (&sn)[KTB][QT], int t, auto steady_tag) {
     constexpr bool STEADY = decltype(steady_tag)::value;
     const bool has_next = STEADY || t + 1 < NT, mask = !STEADY && t + 2 == NT;
     const int s1 = slot == 2 ? 0 : slot + 1, s2 = slot == 0 ? 2 : slot - 1;      // slots of tiles t+1 and t+2 (= t-1)
-    if (t > 0) {
+    if (t > 0 && !(SR_ATTN_DBG & 1)) {
       __syncthreads();                                       // every wave is past iteration t-1: slot s2 is free, tile t+1 visible
       if (t + 2 < NT) lstore(s2);
-      if (t + 3 < NT) gload((t + 3) * KV_TILE);
+      if (t + 3 < NT) gload((t + 3) * KV);
     }
-    uint4 pf[2][QT];
+    uint4 pf[KTB / 2][QT];
     // alpha of tile t (from the previous iteration's rowmax); once the running maxima settle every alpha is exactly 1 and
     // the 12 packed multiplies are skipped (wave-uniform branch ahead of the pipelined body, which stays one block)
-    if (__any(alpha[0] != 1.0f) || __any(alpha[1] != 1.0f)) rescale();
+    if constexpr (LAZY) {
+      bool moved = false;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) moved = moved || delta[qt] != 0.0f;
+      if (__any(moved)) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          alpha[qt] = __builtin_amdgcn_exp2f(-delta[qt]);
+#pragma unroll
+          for (int kt = 0; kt < KTB; ++kt) { sc[kt][qt][0] -= delta[qt]; sc[kt][qt][1] -= delta[qt]; sc[kt][qt][2] -= delta[qt]; sc[kt][qt][3] -= delta[qt]; }
+          // channel d of the Q fragment = -m: rewritten in the lanes that hold it
+          const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(-mrow[qt]));
+#pragma unroll
+          for (int st = 0; st < DQ; ++st)
+            if (st == m_st && g4 == m_g4) qf[qt][st].x = (qf[qt][st].x & 0xffff0000u) | hb;
+          delta[qt] = 0.f;
+        }
+        rescale();
+      }
+    } else {
+      bool resc = false;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) resc = resc || alpha[qt] != 1.0f;
+      if (__any(resc)) rescale();
+    }
     if (has_next) qk(sn, s1);
     expo(sc, pf);
     if constexpr (STEADY) {
 #pragma unroll
-      for (int i = 0; i < 4 * QT * DQ; ++i) {
+      for (int i = 0; i < KTB * QT * DQ; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
       }
     }
     pv(pf, slot);
-    if (has_next) rowmax(sn, (t + 1) * KV_TILE, mask);
+    if (has_next) rowmax(sn, (t + 1) * KV, mask);
     if constexpr (STEADY) {
 #pragma unroll
-      for (int i = 0; i < 2 * DT * QT; ++i) {
+      for (int i = 0; i < (KTB / 2) * DT * QT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 1);
       }
@@ -573,11 +648,12 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   }
 }
 
-template <int DQ, int DT, bool SR, int MB = 2, int NTHR = 256>
+template <int DQ, int DT, bool SR, int MB = 2, int NTHR = 256, bool LAZY = false, int KTB = 4, int QT = 2>
 int launch_pipe(const sr_attention_args& a, hipStream_t st) {
-  dim3 grid(sr_cdiv(a.Tq, (NTHR / 64) * 32), a.heads, a.B);
-  constexpr int lds = 3 * (KV_TILE * 4 * DQ * 16 + DT * 16 * (KV_TILE * 2 + 8));
-  auto k = attn_pipe_kernel<DQ, DT, SR, MB, NTHR>;
+  dim3 grid(sr_cdiv(a.Tq, (NTHR / 64) * 16 * QT), a.heads, a.B);
+  constexpr int KV = 16 * KTB;
+  constexpr int lds = 3 * (KV * 4 * DQ * 16 + DT * 16 * (KV * 2 + 8));
+  auto k = attn_pipe_kernel<DQ, DT, SR, MB, NTHR, LAZY, KTB, QT>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   hipLaunchKernelGGL(k, grid, dim3(NTHR), lds, st, a);
@@ -640,6 +716,15 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
         // eight waves per workgroup (one workgroup per CU instead of two of four waves): every staged K / V^T tile serves
         // twice as many queries, 733 vs 791 us at B16 T4096 d40 on the same box
         static const int nthr = getenv("SR_ATTN_NTHR") ? atoi(getenv("SR_ATTN_NTHR")) : 512;   // tuning aid
+        static const bool lazy = !(getenv("SR_ATTN_LAZY") && atoi(getenv("SR_ATTN_LAZY")) == 0);   // A-B aid
+        static const int ktb = getenv("SR_ATTN_KTB") ? atoi(getenv("SR_ATTN_KTB")) : 4;           // A-B aid: keys per tile / 16
+        // (measured and dropped: 64 queries per wave at one wave per SIMD -- QT = 4 -- needs 512 registers and still spills 1 KB;
+        //  3 or 4 waves per SIMD spill 190-700 B; 32-key tiles (KTB = 2) fit in 218 registers without a spill but double the
+        //  barriers: 847 vs 744 us.  Timing with the per-tile barrier + loads compiled out: 551 us of the 752, with v_exp_f32 replaced by
+        //  a multiply: no change -> the loop is bound by the tile hand-off and by LDS-read / MFMA dependency waits at two waves per
+        //  SIMD, not by the transcendental rate; profiles/r02_attention_pmc.txt)
+        if (nthr == 512 && lazy && ktb == 2) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 2>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 2>(*a, st);
+        if (nthr == 512 && lazy) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true>(*a, st) : launch_pipe<2, 3, false, 2, 512, true>(*a, st);
         if (nthr == 512) return (d & 15) ? launch_pipe<2, 3, true, 2, 512>(*a, st) : launch_pipe<2, 3, false, 2, 512>(*a, st);
         return (d & 15) ? launch_pipe<2, 3, true>(*a, st) : launch_pipe<2, 3, false>(*a, st);
       }

@@ -168,6 +168,16 @@ __global__ void cfg_combine_kernel(const float* __restrict__ x, const float* __r
   if (d) d[i] = (x[i] - r) / sigma;
 }
 
+// DiagonalGaussianDistribution.sample (distributions.py:24-37): moments NHWC [mean(zc) | logvar(zc)] -> z NCHW
+__global__ void vae_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise, float* __restrict__ z, int B, int zc, int HW) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * zc * HW) return;
+  const int p = (int)(i % HW), c = (int)((i / HW) % zc), b = (int)(i / ((int64_t)HW * zc));
+  const float* m = mom + ((int64_t)b * HW + p) * (2 * zc);
+  const float logvar = fminf(fmaxf(m[zc + c], -30.0f), 20.0f);
+  z[i] = m[c] + expf(0.5f * logvar) * noise[i];
+}
+
 __global__ void euler_kernel(float* __restrict__ x, const float* __restrict__ d, int64_t n, float dt) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = x[i] + d[i] * dt;
@@ -319,6 +329,13 @@ extern "C" int sr_cfg_combine(const float* x, const float* out_c, const float* c
   if (!x || !out_c || !cnt_c || !out_u || !cnt_u || !denoised) SR_FAIL(SR_ERR_INVALID, "sr_cfg_combine: null");
   hipLaunchKernelGGL(cfg_combine_kernel, g1(n), dim3(256), 0, sr_stream(stream), x, out_c, cnt_c, out_u, cnt_u, denoised, d, n, sigma, cfg);
   SR_CHECK_LAUNCH("sr_cfg_combine");
+  return SR_OK;
+}
+
+extern "C" int sr_vae_sample(const float* moments, const float* noise, float* z, int32_t B, int32_t zc, int32_t HW, void* stream) {
+  if (!moments || !noise || !z || B < 1 || zc < 1 || HW < 1) SR_FAIL(SR_ERR_INVALID, "sr_vae_sample: bad args");
+  hipLaunchKernelGGL(vae_sample_kernel, g1((int64_t)B * zc * HW), dim3(256), 0, sr_stream(stream), moments, noise, z, B, zc, HW);
+  SR_CHECK_LAUNCH("sr_vae_sample");
   return SR_OK;
 }
 

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
   const int K1 = C1 / KE, KPT = Ctot / KE;             // K-steps from source a / per tap
   const int ntaps = p.KH * p.KH;
   const int KT = ntaps * KPT;
-  const int H = p.H, W = p.W, pad = p.KH >> 1;
+  const int H = p.H, W = p.W, pad = p.pad_br ? 0 : (p.KH >> 1);
   const int rpb = Ho * Wo;
 
   // ---- per-lane row bookkeeping for the X (pixel) tile
@@ -244,7 +244,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     for (int i = 0; i < NIP; ++i) {
       int iy = py[i] + ky, ix = px[i] + kx;
       bool ok = pb[i] >= 0;
-      if (p.upsample) { ok = ok && iy >= 0 && ix >= 0 && iy < 2 * H && ix < 2 * W; iy >>= 1; ix >>= 1; }
+      if (p.upsample) {
+        // nearest upsample fused into the gather: x2, or to an arbitrary (up_h, up_w) with torch's rule src = floor(dst * in/out)
+        // (fp32 scale) -- Upsample.forward(x, output_shape) interpolates to the skip tensor's size (openaimodel.py:109-121)
+        if (p.up_h > 0) {
+          ok = ok && iy >= 0 && ix >= 0 && iy < p.up_h && ix < p.up_w;
+          iy = min((int)floorf((float)iy * ((float)H / (float)p.up_h)), H - 1);
+          ix = min((int)floorf((float)ix * ((float)W / (float)p.up_w)), W - 1);
+          if (!ok) { iy = 0; ix = 0; }
+        } else { ok = ok && iy >= 0 && ix >= 0 && iy < 2 * H && ix < 2 * W; iy >>= 1; ix >>= 1; }
+      }
       else            { ok = ok && iy >= 0 && ix >= 0 && iy < H && ix < W; }
       const int64_t pix = ((int64_t)pb[i] * H + iy) * W + ix;
       rowA[i] = ok ? (const char*)p.a + (pix * C1) * (int64_t)sizeof(T) + lchunk * 16 : zp;
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(512, 1) void conv3p_kernel(const sr_igemm_args p, c
 }
 
 static bool conv3p_ok(const sr_igemm_args& a, int M) {
-  if (a.dtype != SR_F16 || a.KH != 3 || a.stride != 1 || a.upsample || a.C2 || a.transpose_out || a.row_stats) return false;
+  if (a.dtype != SR_F16 || a.KH != 3 || a.stride != 1 || a.upsample || a.C2 || a.transpose_out || a.row_stats || a.pad_br) return false;
   if (a.C1 % 64 || a.N % 320 || M % 256 || a.act == 2) return false;
   const int rpb = a.H * a.W;
   if (a.W < 8 || 256 % a.W) { if (!(rpb < 256 && 256 % rpb == 0)) return false; }
@@ -884,14 +893,20 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->KH != 1 && a->KH != 3) SR_FAIL(SR_ERR_INVALID, "sr_igemm: KH=%d", a->KH);
   if (a->stride != 1 && a->stride != 2) SR_FAIL(SR_ERR_INVALID, "sr_igemm: stride=%d", a->stride);
   if (a->upsample && a->stride != 1) SR_FAIL(SR_ERR_INVALID, "sr_igemm: upsample with stride");
+  if (a->pad_br && (a->KH != 3 || a->upsample)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: pad_br is for 3x3 convs without upsample");
   if (a->N <= 0 || a->B <= 0 || a->H <= 0 || a->W <= 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad sizes");
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
   if (a->row_stats && !a->colsum) SR_FAIL(SR_ERR_INVALID, "sr_igemm: row_stats without colsum");
   if (a->row_stats && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
   if (a->tile < 0 || a->tile > 12 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
-  if (a->upsample) { Ho = 2 * a->H; Wo = 2 * a->W; }
-  else if (a->stride == 2) { Ho = (a->H + 2 * (a->KH / 2) - a->KH) / 2 + 1; Wo = (a->W + 2 * (a->KH / 2) - a->KH) / 2 + 1; }
+  if (a->upsample && ((a->up_h > 0) != (a->up_w > 0))) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w go together");
+  if (!a->upsample && (a->up_h || a->up_w)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w without upsample");
+  if (a->upsample) { Ho = a->up_h > 0 ? a->up_h : 2 * a->H; Wo = a->up_w > 0 ? a->up_w : 2 * a->W; }
+  else if (a->stride == 2) {
+    const int ptot = a->pad_br ? a->KH / 2 : 2 * (a->KH / 2);       // total zero rows / columns added per dimension
+    Ho = (a->H + ptot - a->KH) / 2 + 1; Wo = (a->W + ptot - a->KH) / 2 + 1;
+  }
   else { Ho = a->H; Wo = a->W; }
   const int64_t M64 = (int64_t)a->B * Ho * Wo;
   if (M64 > 0x7fffffffLL / 2) SR_FAIL(SR_ERR_INVALID, "sr_igemm: M too large");

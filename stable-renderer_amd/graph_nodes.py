@@ -159,12 +159,18 @@ class CheckpointLoaderSimple:
             cfg = dict(r.get("unet_cfg") or SD15_CFG)
             unet_sd, vae_sd, clip = r["unet"], r.get("vae"), r.get("clip")
             vae = VAEDecoder(vae_sd, dtype=dt) if (output_vae and vae_sd is not None) else None
+            if vae is not None and r.get("vae_encoder") is not None:
+                from .vae import VAEEncoder
+                vae = VAE(vae, VAEEncoder(r["vae_encoder"], dtype=dt))
         else:                                                    # a full SD1.x checkpoint file
             unet_sd, vae_sd, _ = WT.split_checkpoint(r)
             from .unet import SDXL_CFG
             cfg = dict(SDXL_CFG if "label_emb.0.0.weight" in unet_sd else SD15_CFG)   # (model_detection.py: SDXL carries label_emb)
             clip = None
             vae = VAEDecoder(vae_sd, dtype=dt, prefix="decoder.") if output_vae else None
+            if vae is not None and "encoder.conv_in.weight" in vae_sd:
+                from .vae import VAEEncoder
+                vae = VAE(vae, VAEEncoder(vae_sd, dtype=dt, prefix="encoder."))
         if clip is None:
             clip = _NoCLIP()
         model = N.MODEL(UNet(unet_sd, cfg, dtype=dt), state_dict=unet_sd, cfg=cfg, dtype=dt)
@@ -276,6 +282,80 @@ class KSampler:
         return N.custom_ksampler(model, seed, steps, cfg, sampler_name, scheduler, positive, negative, latent_image, denoise=denoise)
 
 
+class VAE:
+    """What CheckpointLoaderSimple hands out as VAE: the decoder plan object, plus the encoder when the checkpoint has one
+    (comfy/sd.py:196-371 VAE.decode / VAE.encode).  Attribute access falls through to the decoder, so code written against the
+    decoder alone keeps working."""
+
+    def __init__(self, decoder, encoder=None):
+        self.decoder, self.encoder = decoder, encoder
+        self._enc_plans = {}
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["decoder"], name)
+
+    def encode(self, pixels):
+        """pixels (N,H,W,C) in [0,1] -> (N,4,H/8,W/8) fp32; crops to a multiple of 8 as vae_encode_crop_pixels (sd.py:292-299)"""
+        if self.encoder is None:
+            raise ValueError("this VAE came without encoder weights (encoder.* / quant_conv keys)")
+        x = (pixels.shape[1] // 8) * 8
+        y = (pixels.shape[2] // 8) * 8
+        if pixels.shape[1] != x or pixels.shape[2] != y:
+            xo, yo = (pixels.shape[1] % 8) // 2, (pixels.shape[2] % 8) // 2
+            pixels = pixels[:, xo:x + xo, yo:y + yo, :]
+        key = (pixels.shape[0], pixels.shape[1], pixels.shape[2])
+        if key not in self._enc_plans:
+            self._enc_plans[key] = self.encoder.build(*key)
+        return self.encoder.encode(self._enc_plans[key], pixels.to(self.encoder.device))
+
+
+class VAEEncode:
+    """comfyUI/nodes.py:319-332"""
+    RETURN_TYPES = ("LATENT",)
+    FUNCTION = "encode"
+    CATEGORY = "latent"
+
+    @classmethod
+    def INPUT_TYPES(s):
+        return {"required": {"pixels": ("IMAGE",), "vae": ("VAE",)}}
+
+    def encode(self, vae, pixels):
+        if pixels.dim() == 3:
+            pixels = pixels.unsqueeze(0)
+        return (N.LATENT(samples=vae.encode(pixels[:, :, :, :3])),)
+
+
+class LoadImage:
+    """comfyUI/nodes.py:1623-1665 -> (IMAGE (1,H,W,3) in [0,1], MASK = 1 - alpha or 64x64 zeros).  ``image`` is a path, or a name
+    under $SR_INPUT_DIR (the reference's input directory)"""
+    RETURN_TYPES = ("IMAGE", "MASK")
+    FUNCTION = "load_image"
+    CATEGORY = "image"
+
+    @classmethod
+    def INPUT_TYPES(s):
+        return {"required": {"image": ("STRING", {})}}
+
+    def load_image(self, image):
+        import numpy as np
+        from PIL import Image, ImageOps, ImageSequence
+        path = image if os.path.isabs(image) or os.path.exists(image) else os.path.join(os.environ.get("SR_INPUT_DIR", "input"), image)
+        img = Image.open(path)
+        images, masks = [], []
+        for i in ImageSequence.Iterator(img):
+            i = ImageOps.exif_transpose(i)
+            if i.mode == "I":
+                i = i.point(lambda v: v * (1 / 255))
+            images.append(torch.from_numpy(np.array(i.convert("RGB")).astype(np.float32) / 255.0)[None,])
+            if "A" in i.getbands():
+                masks.append((1.0 - torch.from_numpy(np.array(i.getchannel("A")).astype(np.float32) / 255.0)).unsqueeze(0))
+            else:
+                masks.append(torch.zeros((64, 64), dtype=torch.float32).unsqueeze(0))
+        if len(images) > 1:
+            return (torch.cat(images, dim=0), torch.cat(masks, dim=0))
+        return (images[0], masks[0])
+
+
 class VAEDecode(N.VAEDecode):
     """comfyUI/nodes.py:287-303"""
     RETURN_TYPES = ("IMAGE",)
@@ -317,7 +397,7 @@ class IfValTypeEqual(N.StableRenderingNode):
 
 for _name, _cls in (("CheckpointLoaderSimple", CheckpointLoaderSimple), ("LoraLoaderModelOnly", LoraLoaderModelOnly),
                     ("ControlNetLoader", ControlNetLoader), ("ControlNetApply", ControlNetApply), ("CLIPTextEncode", CLIPTextEncode),
-                    ("SceneTextEncode", SceneTextEncode), ("MaskedTextEncode", MaskedTextEncode), ("KSampler", KSampler), ("VAEDecode", VAEDecode),
+                    ("SceneTextEncode", SceneTextEncode), ("MaskedTextEncode", MaskedTextEncode), ("KSampler", KSampler), ("VAEDecode", VAEDecode), ("VAEEncode", VAEEncode), ("LoadImage", LoadImage),
                     ("IsNotNone", IsNotNone), ("If", If), ("IfValTypeEqual", IfValTypeEqual),
                     ("EngineData", N.EngineDataNode), ("VirtualEngineData", N.VirtualEngineDataNode),
                     ("InferenceOutput", N.InferenceOutputNode), ("EmptyCorrMaps", N.EmptyCorrMaps),
@@ -325,3 +405,8 @@ for _name, _cls in (("CheckpointLoaderSimple", CheckpointLoaderSimple), ("LoraLo
                     ("CorrespondSampler", N.CorrespondSampler), ("IDSequenceLoader", N.IDSequenceLoader),
                     ("ImageSequenceLoader", N.ImageSequenceLoader), ("NoiseSequenceLoader", N.NoiseSequenceLoader)):
     register_node(_name, _cls)
+
+
+def register_legacy_aliases():
+    """opt-in: node names of earlier reference revisions that shipped example graphs still use (see nodes.FrameDataNode)"""
+    register_node("FrameData", N.FrameDataNode)

@@ -123,6 +123,40 @@ def vae_decoder_names_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_c
     return out, norms
 
 
+def vae_encoder_names_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, in_channels=3):
+    """Encoder state-dict names/shapes (comfy/ldm/modules/diffusionmodules/model.py:441-500) followed by AutoencoderKL's
+    ``quant_conv`` (comfy/ldm/models/autoencoder.py:160-170, embed_dim = z_channels, double_z)"""
+    out, norms = [], []
+
+    def res(p, cin, cout):
+        out.extend([(f"{p}.norm1.weight", (cin,)), (f"{p}.norm1.bias", (cin,)), (f"{p}.conv1.weight", (cout, cin, 3, 3)),
+                    (f"{p}.conv1.bias", (cout,)), (f"{p}.norm2.weight", (cout,)), (f"{p}.norm2.bias", (cout,)),
+                    (f"{p}.conv2.weight", (cout, cout, 3, 3)), (f"{p}.conv2.bias", (cout,))])
+        norms.extend([f"{p}.norm1.weight", f"{p}.norm2.weight"])
+        if cin != cout:
+            out.extend([(f"{p}.nin_shortcut.weight", (cout, cin, 1, 1)), (f"{p}.nin_shortcut.bias", (cout,))])
+    out += [("conv_in.weight", (ch, in_channels, 3, 3)), ("conv_in.bias", (ch,))]
+    cin = ch
+    for lev in range(len(ch_mult)):
+        cout = ch * ch_mult[lev]
+        for i in range(num_res_blocks):
+            res(f"down.{lev}.block.{i}", cin, cout)
+            cin = cout
+        if lev != len(ch_mult) - 1:
+            out += [(f"down.{lev}.downsample.conv.weight", (cin, cin, 3, 3)), (f"down.{lev}.downsample.conv.bias", (cin,))]
+    res("mid.block_1", cin, cin)
+    out += [("mid.attn_1.norm.weight", (cin,)), ("mid.attn_1.norm.bias", (cin,))]
+    norms.append("mid.attn_1.norm.weight")
+    for n in ("q", "k", "v", "proj_out"):
+        out += [(f"mid.attn_1.{n}.weight", (cin, cin, 1, 1)), (f"mid.attn_1.{n}.bias", (cin,))]
+    res("mid.block_2", cin, cin)
+    out += [("norm_out.weight", (cin,)), ("norm_out.bias", (cin,)), ("conv_out.weight", (2 * z_channels, cin, 3, 3)),
+            ("conv_out.bias", (2 * z_channels,))]
+    norms.append("norm_out.weight")
+    out += [("quant_conv.weight", (2 * z_channels, 2 * z_channels, 1, 1)), ("quant_conv.bias", (2 * z_channels,))]
+    return out, norms
+
+
 def controlnet_names_shapes(cfg, hint_channels=3):
     """cldm.ControlNet state-dict names/shapes (comfy/cldm/cldm.py:30-282) for a UNet config: the UNet's time embedding,
     encoder and middle block, the 8-conv hint encoder (16,16,32,32,96,96,256 -> model_channels), one 1x1 zero conv per

@@ -77,6 +77,20 @@ class EngineDataNode(StableRenderingNode):
                 engine_data.correspond_maps, engine_data.sprite_infos, engine_data.env_prompts)
 
 
+class FrameDataNode(EngineDataNode):
+    """``FrameData``: the 7-output node an earlier revision of the reference had where ``EngineData`` is today; two shipped example
+    graphs (miku-img2img-example-unix.json, miku-controlnet-no-lora-workflow.json) still name it, and the reference itself no
+    longer loads them (Workflow.Load -> ValueError "Cannot find the type FrameData").  NOT registered by default -- same error
+    here; ``graph_nodes.register_legacy_aliases()`` opts in."""
+    N_OUTPUTS = 7
+
+    def __call__(self, engine_data: EngineData):
+        if engine_data is None:
+            return (None,) * 7
+        return (engine_data.color_maps, engine_data.id_maps, engine_data.pos_maps, engine_data.normal_maps,
+                engine_data.depth_maps, engine_data.noise_maps, engine_data.masks)
+
+
 class VirtualEngineDataNode(StableRenderingNode):
     """_nodes/data.py:71-105: build EngineData when running a graph without the engine."""
     PriorNode = True

@@ -87,7 +87,8 @@ def workspace(device, nbytes=64 << 20):
 
 
 def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C2=0, bias=None, rowvec=None,
-               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0, tile=0, split=0, row_stats=None, colsum=None):
+               residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0, tile=0, split=0, row_stats=None, colsum=None,
+               pad_br=0, up_hw=None):
     ar = L.IgemmArgs()
     ar.a, ar.a2, ar.w, ar.bias, ar.rowvec, ar.residual, ar.out = _p(a), _p(a2), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
     ar.zero_page = _p(zero_page(a.device))
@@ -96,7 +97,8 @@ def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C
     ar.dtype = DT[a.dtype if dtype is None else dtype]
     ar.scale = scale
     ar.rowvec_ld = rowvec_ld
-    ar.tile, ar.split = tile, split
+    ar.tile, ar.split, ar.pad_br = tile, split, pad_br
+    ar.up_h, ar.up_w = (0, 0) if (up_hw is None or tuple(up_hw) == (2 * H, 2 * W)) else (int(up_hw[0]), int(up_hw[1]))
     ar.row_stats, ar.colsum = _p(row_stats), _p(colsum)
     ws = workspace(a.device)
     ar.workspace, ar.workspace_bytes = _p(ws), ws.numel()
@@ -127,12 +129,12 @@ def autotune_enabled():
 
 def tune_igemm(ar, min_flops=1.0e9, reps=4, allow_split=True):
     """times the candidate (tile, split) settings of one op on the current stream and leaves the fastest in ``ar``"""
-    Ho, Wo = (2 * ar.H, 2 * ar.W) if ar.upsample else ((ar.H + ar.stride - 1) // ar.stride, (ar.W + ar.stride - 1) // ar.stride)
+    Ho, Wo = ((ar.up_h or 2 * ar.H), (ar.up_w or 2 * ar.W)) if ar.upsample else ((ar.H + ar.stride - 1) // ar.stride, (ar.W + ar.stride - 1) // ar.stride)
     flops = 2.0 * ar.B * Ho * Wo * ar.N * ar.KH * ar.KH * (ar.C1 + ar.C2)
     if flops < min_flops:
         return
     sig = (ar.dtype, ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample, ar.act, ar.transpose_out, ar.out_f32,
-           bool(ar.residual), bool(ar.rowvec), bool(allow_split), bool(ar.row_stats))
+           bool(ar.residual), bool(ar.rowvec), bool(allow_split), bool(ar.row_stats), ar.pad_br, ar.up_h, ar.up_w)
     if sig not in _TUNED:
         lib, st = L.lib(), stream_ptr()
         times = {}
@@ -368,6 +370,12 @@ def cond_accumulate(x, eps, mult, kinds, out_c, cnt_c, out_u, cnt_u, area, chunk
 def cfg_combine(x, out_c, cnt_c, out_u, cnt_u, den, d, sigma, cfg):
     L.check(L.lib().sr_cfg_combine(_p(x), _p(out_c), _p(cnt_c), _p(out_u), _p(cnt_u), _p(den), _p(d), x.numel(), float(sigma),
                                    float(cfg), stream_ptr()))
+
+
+def vae_sample(moments, noise, z):
+    """moments (B,HW,2zc) fp32, noise / z (B,zc,h,w) fp32"""
+    B, zc = z.shape[:2]
+    L.check(L.lib().sr_vae_sample(_p(moments), _p(noise), _p(z), B, zc, z[0, 0].numel(), stream_ptr()))
 
 
 def euler_step(x, d, dt):

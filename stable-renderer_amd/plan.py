@@ -119,7 +119,7 @@ class PlanBuilder:
             O.tune_igemm(ar, allow_split=self._lane == 0)
         self._emit(L.OP_IGEMM, "igemm", ar)
         KH, st, up = kw.get("KH", 1), kw.get("stride", 1), kw.get("upsample", 0)
-        Ho, Wo = (2 * H, 2 * W) if up else ((H + st - 1) // st, (W + st - 1) // st)
+        Ho, Wo = (tuple(kw["up_hw"]) if kw.get("up_hw") else (2 * H, 2 * W)) if up else ((H + st - 1) // st, (W + st - 1) // st)
         f = 2 * B * Ho * Wo * N * KH * KH * (C1 + kw.get("C2", 0))
         self.flops += f
         self.op_flops[-1] = f

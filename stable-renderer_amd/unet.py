@@ -390,10 +390,13 @@ class UNet:
                     cur = stransformer(f"output_blocks.{bo}.1", cur, ch, hh * ww, hh, ww, depth)
                     j = 2
                 if lev > 0 and i == cfg["num_res_blocks"][lev]:
-                    up = pb.buf(B, 4 * hh * ww, ch)
-                    pb.igemm(cur, W[f"output_blocks.{bo}.{j}.conv"], up, B, hh, ww, ch, ch, KH=3, upsample=1,
+                    # Upsample.forward(x, output_shape = hs[-1].shape): nearest to the NEXT skip's size, which is 2x only for
+                    # even sizes (openaimodel.py:109-121; forward_timestep_embed passes output_shape, :59-60)
+                    uh, uw = hs[-1][2], hs[-1][3]
+                    up = pb.buf(B, uh * uw, ch)
+                    pb.igemm(cur, W[f"output_blocks.{bo}.{j}.conv"], up, B, hh, ww, ch, ch, KH=3, upsample=1, up_hw=(uh, uw),
                              bias=W[f"output_blocks.{bo}.{j}.conv.b"])
-                    cur, hh, ww = up, 2 * hh, 2 * ww
+                    cur, hh, ww = up, uh, uw
                 bo += 1
         # ---- out -------------------------------------------------------------------------------------
         n = pb.buf(B, hh * ww, ch)

@@ -354,7 +354,7 @@ def test_masked_text_nodes_feed_the_sampler():
     assert len(pos) == 4 and len(neg) == 1                              # 3 sprite prompts (both signs, as the reference) + env
     assert [("mask" in e[1]) for e in pos] == [True, True, True, False]
     assert pos[1][1]["mask_strength"] == 0.5 and pos[2][1]["mask_strength"] == 0.8
-    assert float(pos[0][1]["mask"].sum()) == 70 * 60
+    assert float(pos[0][1]["mask"].sum()) == 70 * 60 - 30 * 10            # sprite 2 covers a corner of sprite 1
     one = GN.MaskedTextEncode()(clip, "a cat", mask=torch.ones(128, 128), inverse_mask=True, strength=0.3, mode="set_cond_area")
     assert one[0][1]["set_area_to_bounds"] and float(one[0][1]["mask"].abs().sum()) == 0 and one[0][1]["mask"].dim() == 3
     lat = LATENT(samples=torch.zeros(1, 4, 16, 16))

@@ -362,6 +362,32 @@ def test_attention_softmax_spike(ops):
     assert torch.allclose(o.cpu(), ref, atol=5e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("case", ["late_spike", "low_first_tile", "rising", "injected_bk1", "d48"])
+def test_attention_lazy_shift_paths(ops, case):
+    """the pipelined fp16 kernel keeps the softmax shift inside the QK^T MFMA and moves it lazily: force every branch -- a key that
+    tops the running shift by far more than 2^8 late in the sequence, a first tile far BELOW the later ones, maxima that creep up
+    tile after tile, one K/V for the whole batch (Bk = 1), and d = 48 (no spare V^T row: VALU row sum)"""
+    dtype = torch.float16
+    B, T, heads, d = 2, 1024, 8, 48 if case == "d48" else 40
+    q, k, v = rnd(1, B, T, heads * d), rnd(2, B, T, heads * d), rnd(3, B, T, heads * d)
+    if case == "late_spike":
+        k[:, 900] = q[:, 17] * 4.0
+        k[:, 333] = q[:, 600] * 3.0
+    elif case == "low_first_tile":
+        k[:, :64] = -q[:, :64] * 2.0                       # the first tile's scores sit far below the rest for these queries
+    elif case == "rising":
+        k = k * torch.linspace(0.2, 3.0, T).view(1, T, 1)
+    Bk = 1 if case == "injected_bk1" else B
+    qd, kd, vd = q.to(dtype), k[:Bk].to(dtype), v[:Bk].to(dtype)
+    ref = _attn_ref(qd.float(), kd.float().expand(B, -1, -1), vd.float().expand(B, -1, -1), heads)
+    vt = vd.view(Bk, T, heads, d).permute(0, 2, 3, 1).contiguous()
+    o = ops.attention(qd.cuda(), kd.cuda(), vt.cuda(), heads)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    err = (o.float().cpu() - ref).abs().max().item()
+    assert torch.allclose(o.float().cpu(), ref, atol=6e-3, rtol=2e-2), (case, err)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_and_embedding(ops, dtype):
     x = rnd(1, 2, 4, 6, 5)

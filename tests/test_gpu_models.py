@@ -51,6 +51,11 @@ def test_unet_tiny(dtype, atol):
     yi, _ = run_unet(sd, cfg, dtype, T(d["x"]), T(d["t"]), T(d["ctx"]), inject=d["inj_idx"].tolist())
     refi = T(d["y_inj"])
     assert (yi - refi).abs().max().item() < atol * max(1.0, refi.abs().max().item()), (yi - refi).abs().max()
+    # a latent that does not halve evenly (10x12 -> 5x6 -> 3x3 -> 2x2): the upsample fused into the decoder's convs targets the
+    # skip tensor's size (sr_igemm_args.up_h / up_w), as Upsample.forward(x, output_shape) does
+    yo, _ = run_unet(sd, cfg, dtype, T(d["x_odd"]), T(d["t"])[:2], T(d["ctx"])[:2])
+    refo = T(d["y_odd"])
+    assert (yo - refo).abs().max().item() < atol * max(1.0, refo.abs().max().item()), (yo - refo).abs().max()
 
 
 @pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
@@ -115,6 +120,27 @@ def test_vae_decoder(dtype, atol):
     img = p2["img"].cpu()
     assert (img - T(d["img"])).abs().max().item() < atol
     assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
+def test_vae_encoder(dtype, atol):
+    """VAE.encode on the HIP plan (Encoder with the bottom/right-padded stride-2 Downsample convs, quant_conv, posterior sample)
+    vs the reference AutoencoderKL's moments and its sampled z (same global-generator noise)"""
+    from stable_renderer_amd.vae import VAEEncoder
+    d = np.load(os.path.join(GOLD, "vae_enc.npz"))
+    enc = VAEEncoder(_sd("vae_enc_keys.json", 3), dtype=dtype)
+    px = T(d["pixels"])
+    b = enc.build(px.shape[0], px.shape[1], px.shape[2])
+    assert b["latent_hw"] == (8, 8)
+    torch.manual_seed(31)
+    z = enc.encode(b, px.cuda())                                   # draws the posterior noise from the global CPU generator
+    torch.cuda.synchronize()
+    mom = b["moments"].cpu().reshape(px.shape[0], 8, 8, 8).permute(0, 3, 1, 2)
+    ref_m, ref_z = T(d["moments"]), T(d["z"])
+    assert (mom - ref_m).abs().max().item() < atol * max(1.0, ref_m.abs().max().item())
+    assert (z.cpu() - ref_z).abs().max().item() < atol * max(1.0, ref_z.abs().max().item())
+    z2 = enc.encode(b, px.cuda(), noise=T(d["noise"]))
+    assert torch.equal(z2, z)
 
 
 @pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])

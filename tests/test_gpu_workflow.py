@@ -14,7 +14,7 @@ H = W_ = 256                                                    # ControlNetAppl
 def _register(monkeypatch):
     from stable_renderer_amd import synth, weights as WT
     from stable_renderer_amd.graph_nodes import SyntheticCLIP
-    from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes, controlnet_names_shapes
+    from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes, controlnet_names_shapes, vae_encoder_names_shapes
     from stable_renderer_amd.unet import SD15_CFG
     monkeypatch.setenv("SR_DTYPE", "fp32")
     monkeypatch.setenv("SR_AUTOTUNE", "0")                     # same tiles in both plan builds -> bit-identical results
@@ -22,10 +22,11 @@ def _register(monkeypatch):
     ns, norms = unet_names_shapes(cfg)
     vns, vnorms = vae_decoder_names_shapes(ch=32)
     cns, cnorms = controlnet_names_shapes(cfg)
+    ens, enorms = vae_encoder_names_shapes(ch=32)
     WT.clear_registry()
     WT.register_checkpoint("dreamshaper_8.safetensors", lambda: dict(
         unet=synth.synth_state_dict(ns, seed=1, norm_names=norms), vae=synth.synth_state_dict(vns, seed=3, norm_names=vnorms),
-        clip=SyntheticCLIP(ctx_dim=64), unet_cfg=cfg))
+        vae_encoder=synth.synth_state_dict(ens, seed=4, norm_names=enorms), clip=SyntheticCLIP(ctx_dim=64), unet_cfg=cfg))
     for i, name in enumerate(("control_v11f1p_sd15_depth_fp16.safetensors", "control_v11p_sd15_normalbae_fp16.safetensors")):
         WT.register_controlnet(name, lambda i=i: dict(state_dict=synth.synth_state_dict(cns, seed=20 + i, norm_names=cnorms), cfg=cfg))
     g = torch.Generator().manual_seed(9)
@@ -120,6 +121,47 @@ def test_other_shipped_graphs_run(graph, monkeypatch):
         assert (written > 0) == (graph != "miku-control")          # only the CorrespondSampler graphs carry the bake callback
         outs.append(img)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_img2img_graph_runs_end_to_end(monkeypatch, tmp_path):
+    """miku-img2img-example-unix.json (the 'img2img' of the headline metric): FrameData colour -> VAEEncode -> KSampler (lcm, 4 steps,
+    cfg 2, denoise 0.55) -> VAEDecode -> InferenceOutput, and its LoadImage -> VAEEncode branch when the engine sends no colour.
+    The reference's HEAD cannot load this graph (it names the legacy ``FrameData`` node): the alias is opted into here."""
+    import numpy as np
+    from PIL import Image
+    from stable_renderer_amd import graph_nodes as G, workflow as W
+    _register(monkeypatch)
+    monkeypatch.setitem(W.NODE_CLASS_MAPPINGS, "FrameData", None)
+    W.NODE_CLASS_MAPPINGS.pop("FrameData")
+    path = os.path.join(WF, "miku-img2img-example-unix.json")
+    with pytest.raises(ValueError, match="Cannot find the type"):
+        W.Workflow.Load(path)                                           # as the reference, without the alias
+    G.register_legacy_aliases()
+    try:
+        ed = _engine_data(3, N=1)
+        torch.manual_seed(11)
+        ctx = W.run_workflow(path, engine_data=ed, executor=W.PromptExecutor(dev_mode=True))
+        assert ctx.success, getattr(ctx, "error", None)
+        img = ctx.final_output.frame_color.clone()
+        assert tuple(img.shape) == (1, H, W_, 3) and bool(torch.isfinite(img).all()) and 0 <= float(img.min()) and float(img.max()) <= 1
+        # denoise 0.55 keeps the encoded frame's structure: the result moves when the input colour moves
+        ed2 = _engine_data(3, N=1)
+        ed2.color_maps = 1.0 - ed2.color_maps
+        torch.manual_seed(11)
+        ctx2 = W.run_workflow(path, engine_data=ed2, executor=W.PromptExecutor(dev_mode=True))
+        assert (ctx2.final_output.frame_color - img).abs().max().item() > 1e-3
+        # no colour from the engine: If(IsNotNone(color)) takes the LoadImage branch
+        rgb = (np.random.RandomState(0).rand(H, W_, 3) * 255).astype(np.uint8)
+        Image.fromarray(rgb).save(tmp_path / "newplot-2.png")
+        monkeypatch.setenv("SR_INPUT_DIR", str(tmp_path))
+        ed3 = _engine_data(3, N=1)
+        ed3.color_maps = None
+        torch.manual_seed(11)
+        ctx3 = W.run_workflow(path, engine_data=ed3, executor=W.PromptExecutor(dev_mode=True))
+        assert ctx3.success and tuple(ctx3.final_output.frame_color.shape) == (1, H, W_, 3)
+        assert "28" in ctx3.executed_node_ids and "27" in ctx3.executed_node_ids        # LoadImage + its VAEEncode ran
+    finally:
+        W.NODE_CLASS_MAPPINGS.pop("FrameData", None)
 
 
 def test_loaders_are_cached_across_frames(monkeypatch):

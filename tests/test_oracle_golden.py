@@ -151,6 +151,8 @@ def test_unet_tiny(gold):
         yi = O.unet_forward(sd, TINY, T(d["x"]), T(d["t"]), T(d["ctx"]), inject_idx=d["inj_idx"])
         assert torch.allclose(yi, T(d["y_inj"]), atol=2e-4, rtol=1e-4)
         assert not torch.allclose(yi, y, atol=1e-3)
+        yo = O.unet_forward(sd, TINY, T(d["x_odd"]), T(d["t"])[:2], T(d["ctx"])[:2])       # 10x12: Upsample targets the skip's size
+        assert torch.allclose(yo, T(d["y_odd"]), atol=2e-4, rtol=1e-4), (yo - T(d["y_odd"])).abs().max()
 
 
 @pytest.mark.slow
@@ -256,3 +258,18 @@ def test_cond_composition_vs_reference(gold):
         assert torch.allclose(u, T(d[f"{name}_uncond"]), atol=1e-6, rtol=1e-6), name
         r = O.sampling_function(toy_model, x, sigma, n, p, m["scale"])
         assert torch.allclose(r, T(d[f"{name}_cfg"]), atol=1e-5, rtol=1e-6), name
+
+
+def test_vae_encoder_vs_reference(gold):
+    """Encoder + quant_conv + posterior sample (VAE.encode, sd.py:353-371) against the reference AutoencoderKL"""
+    d = gold("vae_enc")
+    with open(os.path.join(GOLD, "vae_enc_keys.json")) as f:
+        k = json.load(f)
+    sd = synth.synth_state_dict([(n, tuple(s)) for n, s in k["names_shapes"]], seed=3, norm_names=k["norm_names"])
+    with torch.no_grad():
+        mom = O.vae_encoder_moments(sd, T(d["pixels"]).movedim(-1, 1) * 2.0 - 1.0)
+        assert torch.allclose(mom, T(d["moments"]), atol=2e-4, rtol=1e-4)
+        torch.manual_seed(31)
+        z = O.vae_encode(sd, T(d["pixels"]))                       # same global-generator draw as the reference
+        assert torch.allclose(z, T(d["z"]), atol=2e-4, rtol=1e-4)
+        assert torch.allclose(O.vae_encode(sd, T(d["pixels"]), noise=T(d["noise"])), z, atol=1e-6)
