@@ -303,6 +303,11 @@ typedef struct {
   const void* noise_tex; int32_t noise_w, noise_h;          /* RGBA16F NEAREST or NULL */
   const void* diffuse_tex; int32_t diffuse_w, diffuse_h;    /* RGBA32F NEAREST or NULL */
   const void* corrmap_tex; int32_t corr_w, corr_h;          /* fp16 (k*k, h, w, 4) for render_mode 1 or NULL */
+  /* tangent-space normal map (default_Gbuffer.frag.glsl:114-123, vert.glsl:52-53): all three or none.  view normal =
+   * normalize(MV_IT * normalize(TBN * normalize(tex.rgb*2-1))), TBN columns = interpolated normalize(tangent), normalize(bitangent),
+   * raw normal */
+  const float* tangent; const float* bitangent;             /* per-vertex [nv,3] fp32 or NULL */
+  const void* normal_tex; int32_t normal_w, normal_h;       /* RGBA32F NEAREST or NULL */
 } sr_draw;
 typedef struct {
   void* color;      /* [H,W,4] fp16 */

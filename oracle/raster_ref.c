@@ -39,6 +39,8 @@ typedef struct {
   const uint16_t* noise_tex; int32_t noise_w, noise_h;
   const float* diffuse_tex; int32_t diffuse_w, diffuse_h;
   const uint16_t* corrmap_tex; int32_t corr_w, corr_h;
+  const float* tangent; const float* bitangent;              /* per-vertex, for the TBN normal-map branch (frag:118-122) */
+  const float* normal_tex; int32_t normal_w, normal_h;       /* RGBA32F */
 } ref_draw;
 
 typedef struct {
@@ -197,6 +199,29 @@ void ref_raster_draw(const ref_draw* d, ref_gbuffer* g) {
       const float depth = 1.0f - zf;
       float n[3] = {vn[0], vn[1], vn[2]};
       normalize3(n);
+      if (d->normal_tex && d->tangent && d->bitangent) {
+        /* frag:118-122 with the varyings of vert:49-53: modelTangent / modelBitangent are normalised per vertex, modelNormal
+           is the raw attribute; all three are interpolated perspective-correct like every other varying */
+        float T3[3][3], B3[3][3], N3[3][3];
+        for (int k = 0; k < 3; ++k) {
+          const int idx = d->tris[3 * t + k];
+          for (int c = 0; c < 3; ++c) { T3[k][c] = d->tangent[3 * idx + c]; B3[k][c] = d->bitangent[3 * idx + c]; N3[k][c] = d->normal[3 * idx + c]; }
+          normalize3(T3[k]); normalize3(B3[k]);
+        }
+        float mt[3], mb[3], mn[3];
+        for (int c = 0; c < 3; ++c) { mt[c] = INTERP(T3[0][c], T3[1][c], T3[2][c]); mb[c] = INTERP(B3[0][c], B3[1][c], B3[2][c]); mn[c] = INTERP(N3[0][c], N3[1][c], N3[2][c]); }
+        const int ntx = nearest_index(uv[0], d->normal_w), nty = nearest_index(uv[1], d->normal_h);
+        const float* tp = d->normal_tex + ((size_t)nty * d->normal_w + ntx) * 4;
+        float c3[3] = {tp[0] * 2.0f - 1.0f, tp[1] * 2.0f - 1.0f, tp[2] * 2.0f - 1.0f};
+        normalize3(c3);
+        float m3[3];
+        for (int c = 0; c < 3; ++c) m3[c] = (mt[c] * c3[0] + mb[c] * c3[1]) + mn[c] * c3[2];
+        normalize3(m3);
+        float v4[4];
+        mat_vec(d->MV_IT, m3[0], m3[1], m3[2], 0.0f, v4);
+        n[0] = v4[0]; n[1] = v4[1]; n[2] = v4[2];
+        normalize3(n);
+      }
       float outND[4] = {n[0] * 0.5f + 0.5f, n[1] * 0.5f + 0.5f, n[2] * 0.5f + 0.5f, depth};
       int32_t real_vid;
       if (!d->use_texcoord_id) real_vid = v[2].vid;                      /* flat: provoking (last) vertex */

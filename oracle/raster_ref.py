@@ -15,7 +15,8 @@ class RefDraw(C.Structure):
                 ("material_id", i32), ("corrmap_k", i32), ("use_texcoord_id", i32), ("render_mode", i32),
                 ("has_vertex_color", i32), ("depth_test", i32), ("cull_back", i32), ("id_w", i32), ("id_h", i32),
                 ("noise_tex", vp), ("noise_w", i32), ("noise_h", i32), ("diffuse_tex", vp), ("diffuse_w", i32),
-                ("diffuse_h", i32), ("corrmap_tex", vp), ("corr_w", i32), ("corr_h", i32)]
+                ("diffuse_h", i32), ("corrmap_tex", vp), ("corr_w", i32), ("corr_h", i32),
+                ("tangent", vp), ("bitangent", vp), ("normal_tex", vp), ("normal_w", i32), ("normal_h", i32)]
 
 
 class RefGBuffer(C.Structure):
@@ -60,7 +61,7 @@ class GBufferRef:
     def clear(self):
         lib().ref_gbuffer_clear(C.byref(self.c))
 
-    def draw(self, task, uniforms, noise_tex=None, diffuse_tex=None, corrmap_tex=None, corr_hw=(0, 0)):
+    def draw(self, task, uniforms, noise_tex=None, diffuse_tex=None, corrmap_tex=None, corr_hw=(0, 0), normal_tex=None):
         """task: stable_renderer_amd.scene.DrawTask (host numpy mesh); uniforms: scene.draw_params(...)"""
         m = task.mesh
         d = RefDraw()
@@ -78,5 +79,9 @@ class GBufferRef:
             d.diffuse_tex, d.diffuse_h, d.diffuse_w = _np(diffuse_tex), diffuse_tex.shape[0], diffuse_tex.shape[1]
         if corrmap_tex is not None:
             d.corrmap_tex, d.corr_h, d.corr_w = _np(corrmap_tex), corr_hw[0], corr_hw[1]
+        if normal_tex is not None:                      # (H, W, 4) float32; the mesh must carry tangents (Mesh.compute_tangents)
+            keep += [normal_tex, m.tangents, m.bitangents]
+            d.normal_tex, d.normal_h, d.normal_w = _np(normal_tex), normal_tex.shape[0], normal_tex.shape[1]
+            d.tangent, d.bitangent = _np(m.tangents), _np(m.bitangents)
         lib().ref_raster_draw(C.byref(d), C.byref(self.c))
         del keep

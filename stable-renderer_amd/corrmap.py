@@ -16,6 +16,9 @@ from . import ops as O
 UpdateMode = Literal['replace', 'replace_avg', 'first', 'first_avg']
 
 
+DEFAULT_DEVICE = "cuda"          # a dry-run Engine (no GPU: scene inspection only) switches this to "cpu"
+
+
 class IDMap:
     """(N, H, W, 4) int32 ``(spriteID, materialID, map_index, vertexID)``; mask = map_index==2048 or all-zero
     (corrmap.py:119-126).  NB the reference's ``height``/``width`` properties return ``shape[-2]``/``shape[-1]``
@@ -100,11 +103,11 @@ class IDMap:
 class CorrespondMap:
     """values (k*k, H*W, C) fp16 + written flags (corrmap.py:372-412), update() = corrmap.py:578-736."""
 
-    def __init__(self, k=3, height=512, width=512, channel_count=4, name=None, device="cuda"):
+    def __init__(self, k=3, height=512, width=512, channel_count=4, name=None, device=None):
         if channel_count != 4:
             raise ValueError("only RGBA corr-maps are supported by the HIP path")
         self.k, self.height, self.width, self.channel_count, self.name = k, height, width, channel_count, name
-        self.device = torch.device(device)
+        self.device = torch.device(device or DEFAULT_DEVICE)
         self._values = torch.zeros(k * k, height * width, channel_count, dtype=torch.float16, device=self.device)
         self._writtens = torch.zeros(k * k, height * width, dtype=torch.uint8, device=self.device)
         self._winner = torch.empty(k * k * height * width, dtype=torch.int32, device=self.device)
@@ -160,7 +163,7 @@ class CorrespondMap:
         return real_path
 
     @classmethod
-    def Load(cls, path, name=None, device="cuda"):
+    def Load(cls, path, name=None, device=None):
         import io
         from PIL import Image
         if os.path.isfile(path):

@@ -323,7 +323,10 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
 #ifndef SR_ATTN_DBG
 #define SR_ATTN_DBG 0        // development only: 1 = no per-tile barrier / loads (timing of the compute alone; wrong results),
 #endif                       // 2 = exp replaced by a multiply, 3 = both
-template <int DQ, int DT, bool SR, int MB, int NTHR = 256, bool LAZY = false, int KTB = 4, int QT = 2>
+// STG: tiles per workgroup barrier.  The ring holds 3*STG slots; tile u (slot u % (3*STG)) is written during iteration u - 2*STG
+// and read in iterations u-1 (QK^T) and u (PV), the barrier stands at every STG-th iteration: between the last read of a slot's
+// previous tile (iteration u - 3*STG) and its rewrite, and between the write and the first read, there is always one.
+template <int DQ, int DT, bool SR, int MB, int NTHR = 256, bool LAZY = false, int KTB = 4, int QT = 2, int STG = 1>
 __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_args p) {
   using T = _Float16;
   constexpr int EPC = 8;
@@ -544,11 +547,12 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
     }
   };
 
-  // ---- prologue: tiles 0..2 into the ring, tile 3 in registers, S(0) and its row max
-  gload(0); lstore(0);
-  if (NT > 1) { gload(KV); lstore(1); }
-  if (NT > 2) { gload(2 * KV); lstore(2); }
-  if (NT > 3) gload(3 * KV);
+  // ---- prologue: tiles 0..2*STG into the ring, tile 2*STG+1 in registers, S(0) and its row max
+  constexpr int NS = 3 * STG;
+#pragma unroll
+  for (int u = 0; u <= 2 * STG; ++u)
+    if (u < NT) { gload(u * KV); lstore(u); }
+  if (2 * STG + 1 < NT) gload((2 * STG + 1) * KV);
   __syncthreads();
   f32x4 sA[KTB][QT], sB[KTB][QT];
   qk(sA, 0);
@@ -559,11 +563,12 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   auto iter = [&](f32x4 (&sc)[KTB][QT], f32x4 (&sn)[KTB][QT], int t, auto steady_tag) {
     constexpr bool STEADY = decltype(steady_tag)::value;
     const bool has_next = STEADY || t + 1 < NT, mask = !STEADY && t + 2 == NT;
-    const int s1 = slot == 2 ? 0 : slot + 1, s2 = slot == 0 ? 2 : slot - 1;      // slots of tiles t+1 and t+2 (= t-1)
+    const int s1 = slot == NS - 1 ? 0 : slot + 1;            // slot of tile t+1
+    const int s2 = slot + 2 * STG >= NS ? slot + 2 * STG - NS : slot + 2 * STG;   // slot of tile t + 2*STG (its old tile: t - STG)
     if (t > 0 && !(SR_ATTN_DBG & 1)) {
-      __syncthreads();                                       // every wave is past iteration t-1: slot s2 is free, tile t+1 visible
-      if (t + 2 < NT) lstore(s2);
-      if (t + 3 < NT) gload((t + 3) * KV);
+      if (STG == 1 || t % STG == 0) __syncthreads();         // every wave is past iteration t-1 (see the slot timing above)
+      if (t + 2 * STG < NT) lstore(s2);
+      if (t + 2 * STG + 1 < NT) gload((t + 2 * STG + 1) * KV);
     }
     uint4 pf[KTB / 2][QT];
     // alpha of tile t (from the previous iteration's rowmax); once the running maxima settle every alpha is exactly 1 and
@@ -648,12 +653,12 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   }
 }
 
-template <int DQ, int DT, bool SR, int MB = 2, int NTHR = 256, bool LAZY = false, int KTB = 4, int QT = 2>
+template <int DQ, int DT, bool SR, int MB = 2, int NTHR = 256, bool LAZY = false, int KTB = 4, int QT = 2, int STG = 1>
 int launch_pipe(const sr_attention_args& a, hipStream_t st) {
   dim3 grid(sr_cdiv(a.Tq, (NTHR / 64) * 16 * QT), a.heads, a.B);
   constexpr int KV = 16 * KTB;
-  constexpr int lds = 3 * (KV * 4 * DQ * 16 + DT * 16 * (KV * 2 + 8));
-  auto k = attn_pipe_kernel<DQ, DT, SR, MB, NTHR, LAZY, KTB, QT>;
+  constexpr int lds = 3 * STG * (KV * 4 * DQ * 16 + DT * 16 * (KV * 2 + 8));
+  auto k = attn_pipe_kernel<DQ, DT, SR, MB, NTHR, LAZY, KTB, QT, STG>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   hipLaunchKernelGGL(k, grid, dim3(NTHR), lds, st, a);
@@ -723,6 +728,10 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
         //  barriers: 847 vs 744 us.  Timing with the per-tile barrier + loads compiled out: 551 us of the 752, with v_exp_f32 replaced by
         //  a multiply: no change -> the loop is bound by the tile hand-off and by LDS-read / MFMA dependency waits at two waves per
         //  SIMD, not by the transcendental rate; profiles/r02_attention_pmc.txt)
+        static const int stg = getenv("SR_ATTN_STG") ? atoi(getenv("SR_ATTN_STG")) : 1;           // A-B aid: tiles per barrier
+        if (nthr == 512 && lazy && ktb == 4 && stg == 2) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 4, 2, 2>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 4, 2, 2>(*a, st);
+        if (nthr == 512 && lazy && ktb == 4 && stg == 3) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 4, 2, 3>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 4, 2, 3>(*a, st);
+        if (nthr == 512 && lazy && ktb == 2 && stg == 4) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 2, 2, 4>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 2, 2, 4>(*a, st);
         if (nthr == 512 && lazy && ktb == 2) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 2>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 2>(*a, st);
         if (nthr == 512 && lazy) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true>(*a, st) : launch_pipe<2, 3, false, 2, 512, true>(*a, st);
         if (nthr == 512) return (d & 15) ? launch_pipe<2, 3, true, 2, 512>(*a, st) : launch_pipe<2, 3, false, 2, 512>(*a, st);

@@ -255,6 +255,36 @@ __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gb
           const float depth = 1.0f - zf;
           float n[3] = {vn[0], vn[1], vn[2]};
           normalize3(n);
+          if (d.normal_tex && d.tangent && d.bitangent) {
+            // TBN normal-map branch (frag.glsl:118-122): the three extra varyings are fetched per covering fragment from the
+            // vertex arrays (L2 resident) instead of widening every TriRec for a branch few materials take
+            const int tri = sbin[s0 + j];
+            float mt[3], mb[3], mn[3];
+            float T3[3][3], B3[3][3], N3[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const int idx = d.tris[3 * tri + k];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { T3[k][c] = d.tangent[3 * idx + c]; B3[k][c] = d.bitangent[3 * idx + c]; N3[k][c] = d.normal[3 * idx + c]; }
+              normalize3(T3[k]); normalize3(B3[k]);
+            }
+#define INTERP2(a0, a1, a2) ((((a0) * f0 + (a1) * f1) + (a2) * f2) / fs)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { mt[c] = INTERP2(T3[0][c], T3[1][c], T3[2][c]); mb[c] = INTERP2(B3[0][c], B3[1][c], B3[2][c]); mn[c] = INTERP2(N3[0][c], N3[1][c], N3[2][c]); }
+#undef INTERP2
+            const int ntx = nearest_index(uv[0], d.normal_w), nty = nearest_index(uv[1], d.normal_h);
+            const float4 tp = ((const float4*)d.normal_tex)[(size_t)nty * d.normal_w + ntx];
+            float c3[3] = {tp.x * 2.0f - 1.0f, tp.y * 2.0f - 1.0f, tp.z * 2.0f - 1.0f};
+            normalize3(c3);
+            float m3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) m3[c] = (mt[c] * c3[0] + mb[c] * c3[1]) + mn[c] * c3[2];
+            normalize3(m3);
+            float v4[4];
+            mat_vec(d.MV_IT, m3[0], m3[1], m3[2], 0.0f, v4);
+            n[0] = v4[0]; n[1] = v4[1]; n[2] = v4[2];
+            normalize3(n);
+          }
           float outND[4] = {n[0] * 0.5f + 0.5f, n[1] * 0.5f + 0.5f, n[2] * 0.5f + 0.5f, depth};
           int real_vid;
           if (!d.use_texcoord_id) real_vid = T.vid;
@@ -381,6 +411,8 @@ extern "C" int sr_raster_draw(const sr_draw* d, const sr_gbuffer* g, void* scrat
   if (scratch_bytes < sr_raster_scratch_bytes(d->nt, g->W, g->H)) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: scratch too small");
   if (d->render_mode != 0 && d->corrmap_k <= 0) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: corrmap_k");
   if (d->use_texcoord_id && (d->id_w <= 0 || d->id_h < 0)) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: id grid size");
+  if (d->normal_tex && (!d->tangent || !d->bitangent || !d->uv || d->normal_w <= 0 || d->normal_h <= 0))
+    SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: a normal map needs uvs, tangents and bitangents");
   hipStream_t st = sr_stream(stream);
   TriRec* recs = (TriRec*)scratch;
   hipLaunchKernelGGL(raster_setup, dim3((d->nt + 255) / 256), dim3(256), 0, st, *d, recs, g->W, g->H);

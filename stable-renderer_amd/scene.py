@@ -104,12 +104,53 @@ class Mesh:
         self.cullback = cullback
         self.name = name
         self._dev = None
+        self.has_uvs = bool(np.any(self.uvs != 0))
+        self.groups = None                 # [(material name, first triangle, triangle count)] of an OBJ with `usemtl` parts
+        self.materials = []                # [{"NAME": ...}] in group order (what assimp reports, mesh.py:360-372)
+        self.tangents = None               # per-vertex tangent / bitangent (only needed when a normal map is bound)
+        self.bitangents = None
+        self._group_meshes = {}
+
+    def group_mesh(self, i):
+        """the sub-mesh drawn with material slot i (mesh.draw(slot), mesh.py:300-318); shares the vertex arrays"""
+        if not self.groups or i >= len(self.groups):
+            return None
+        if i not in self._group_meshes:
+            _, t0, n = self.groups[i]
+            m = Mesh(self.positions, self.normals, self.uvs, self.tris[t0:t0 + n], self.colors, self.vertex_ids, self.cullback,
+                     name=f"{self.name}#{i}")
+            m.tangents, m.bitangents = self.tangents, self.bitangents
+            self._group_meshes[i] = m
+        return self._group_meshes[i]
+
+    def compute_tangents(self):
+        """per-vertex tangent space from the uv gradients, accumulated over the triangles and normalised: the construction of
+        assimp's aiProcess_CalcTangentSpace (mesh.py:337-338 loads with it), without its smoothing-angle vertex splits --
+        parity unpinned (assimp is absent), it only matters when a normal map is bound"""
+        if self.tangents is not None:
+            return
+        P, U = self.positions.astype(np.float64), self.uvs.astype(np.float64)
+        T, B = np.zeros_like(P), np.zeros_like(P)
+        for a, b, c in self.tris:
+            e1, e2 = P[b] - P[a], P[c] - P[a]
+            d1, d2 = U[b] - U[a], U[c] - U[a]
+            det = d1[0] * d2[1] - d2[0] * d1[1]
+            if abs(det) < 1e-20:
+                continue
+            t = (e1 * d2[1] - e2 * d1[1]) / det
+            bt = (e2 * d1[0] - e1 * d2[0]) / det
+            for v in (a, b, c):
+                T[v] += t
+                B[v] += bt
+        nz = lambda v: v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-20)
+        self.tangents, self.bitangents = np.ascontiguousarray(nz(T), F), np.ascontiguousarray(nz(B), F)
+        self._dev = None
 
     def device(self, dev):
         if self._dev is None:
             t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
             self._dev = dict(pos=t(self.positions), normal=t(self.normals), uv=t(self.uvs), tris=t(self.tris),
-                             color=t(self.colors), vid=t(self.vertex_ids))
+                             color=t(self.colors), vid=t(self.vertex_ids), tangent=t(self.tangents), bitangent=t(self.bitangents))
         return self._dev
 
     @staticmethod
@@ -147,11 +188,13 @@ class Mesh:
         return Mesh(pos, nrm, uv, tris, name="plane")
 
     @staticmethod
-    def Load(path):
-        """Wavefront OBJ (positions / uvs / normals, polygons fan-triangulated).  The reference loads through assimp
-        (Triangulate | CalcTangentSpace | JoinIdenticalVertices, mesh.py:337-338), whose vertex order is not
-        reproducible without assimp: vertices here are unique (v, vt, vn) triples in first-use order."""
+    def Load(path, alias=None, cullback=True, **kw):
+        """Wavefront OBJ (positions / uvs / normals, polygons fan-triangulated, `usemtl` parts kept as material groups).  The
+        reference loads through assimp (Triangulate | CalcTangentSpace | JoinIdenticalVertices, mesh.py:321-408), whose vertex
+        order is not reproducible without assimp: vertices here are unique (v, vt, vn) triples in first-use order, triangles are
+        regrouped by material in first-use order (assimp splits a mesh per material the same way)."""
         vs, vts, vns, verts, index, tris = [], [], [], [], {}, []
+        tri_mat, mat_names, cur_mat = [], [], None
         with open(path) as f:
             for line in f:
                 p = line.split()
@@ -163,6 +206,10 @@ class Mesh:
                     vts.append((float(p[1]), float(p[2])))
                 elif p[0] == "vn":
                     vns.append(tuple(map(float, p[1:4])))
+                elif p[0] == "usemtl":
+                    cur_mat = " ".join(p[1:])
+                    if cur_mat not in mat_names:
+                        mat_names.append(cur_mat)
                 elif p[0] == "f":
                     ids = []
                     for tok in p[1:]:
@@ -174,6 +221,7 @@ class Mesh:
                         ids.append(index[key])
                     for k in range(1, len(ids) - 1):
                         tris.append((ids[0], ids[k], ids[k + 1]))
+                        tri_mat.append(cur_mat)
         fix = lambda i, n: i - 1 if i > 0 else n + i
         pos = [vs[fix(a, len(vs))] for a, _, _ in verts]
         uv = [vts[fix(b, len(vts))] if b else (0.0, 0.0) for _, b, _ in verts]
@@ -186,7 +234,21 @@ class Mesh:
                 n = np.cross(P[b] - P[a], P[c] - P[a])
                 nrm[a] += n; nrm[b] += n; nrm[c] += n
             nrm = nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
-        return Mesh(pos, nrm, uv, tris, name=path)
+        groups = None
+        if len(mat_names) > 1 or (mat_names and None not in tri_mat):
+            order = [n for n in ([None] if None in tri_mat else []) + mat_names]
+            new_tris, groups = [], []
+            for n in order:
+                part = [t for t, m_ in zip(tris, tri_mat) if m_ == n]
+                if part:
+                    groups.append((n, len(new_tris), len(part)))
+                    new_tris += part
+            tris = new_tris
+        m = Mesh(pos, nrm, uv, tris, cullback=cullback, name=alias or str(path))
+        if groups:
+            m.groups = groups
+            m.materials = [{"NAME": g[0]} for g in groups if g[0] is not None]
+        return m
 
 
 class Camera:
@@ -210,11 +272,12 @@ class DrawTask:
 
     def __init__(self, mesh, model, sprite_id=1, material_id=1, render_mode=0, corrmap_k=3, use_texcoord_id=False,
                  id_size=(512, 512), noise_tex=None, diffuse_tex=None, corrmap=None, order=RenderOrder.OPAQUE,
-                 has_vertex_color=False):
+                 has_vertex_color=False, normal_tex=None):
         self.mesh, self.model = mesh, np.asarray(model, F)
         self.sprite_id, self.material_id, self.render_mode, self.corrmap_k = sprite_id, material_id, render_mode, corrmap_k
         self.use_texcoord_id, self.id_size = use_texcoord_id, id_size
         self.noise_tex, self.diffuse_tex, self.corrmap = noise_tex, diffuse_tex, corrmap
+        self.normal_tex = normal_tex                      # tangent-space normal map (frag.glsl:114-123); needs mesh tangents
         self.order, self.has_vertex_color = order, has_vertex_color
 
 
@@ -249,6 +312,8 @@ class GBuffer:
 
     def draw(self, task, view, proj):
         dev = self.color.device
+        if task.normal_tex is not None and task.mesh.tangents is None:       # TBN branch: tangents made on first use (mesh.py:337)
+            task.mesh.compute_tangents()
         md = task.mesh.device(dev)
         up = draw_params(task, view, proj)
         d = L.Draw()
@@ -273,6 +338,10 @@ class GBuffer:
                 raise ValueError(f"{name} must be (H, W, 4)")
             return t
         ntex, dtex = dev_tex("noise_tex", torch.float16), dev_tex("diffuse_tex", torch.float32)
+        nmtex = dev_tex("normal_tex", torch.float32)
+        if nmtex is not None:
+            d.tangent, d.bitangent = O._p(md["tangent"]), O._p(md["bitangent"])
+            d.normal_tex, d.normal_h, d.normal_w = O._p(nmtex), nmtex.shape[0], nmtex.shape[1]
         if ntex is not None:
             d.noise_tex, d.noise_h, d.noise_w = O._p(ntex), ntex.shape[0], ntex.shape[1]
         if dtex is not None:

@@ -147,3 +147,44 @@ def test_boatlike_obj_through_mesh_load_bit_exact(frame):
     assert np.array_equal(gb.noise.cpu().numpy().view(np.uint16), ref.noise)
     assert np.array_equal(gb.pos.cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
     assert np.array_equal(gb.canny.cpu().numpy(), ref.canny)
+
+
+def test_normal_map_tbn_branch_bit_exact():
+    """hasNormalTex branch of the fragment shader (frag.glsl:114-123): per-vertex tangent space (Mesh.compute_tangents), a tangent-
+    space normal texture, view normal = normalize(MV_IT * normalize(TBN * normalize(tex*2-1))): normal+depth and canny planes (and
+    the corr-map index they drive) bit exact vs oracle/raster_ref.c, and different from the mesh-normal result"""
+    import os
+    import raster_ref as R
+    from stable_renderer_amd import scene as S
+    W = H = 256
+    cam = S.Camera((0, 3, -3), (0, 0, 0))
+    mesh = S.Mesh.Load(os.path.join(os.path.dirname(__file__), "golden", "boatlike.obj"))
+    g = torch.Generator().manual_seed(8)
+    nmap = torch.rand(32, 32, 4, generator=g)
+    nmap[..., 2] = 0.6 + 0.4 * nmap[..., 2]                              # mostly +z, as tangent-space normal maps are
+    diffuse = torch.rand(16, 16, 4, generator=g)
+    diffuse[..., 3] = 1.0
+    model = S.rotate_y(20.0)
+
+    def render(with_map, mode):
+        t = S.DrawTask(mesh, model, sprite_id=3, material_id=2, render_mode=mode, corrmap_k=6, use_texcoord_id=True, id_size=(W, H),
+                       diffuse_tex=diffuse, normal_tex=nmap if with_map else None, order=999.0)
+        gb = S.GBuffer(W, H)
+        gb.render([t], cam)
+        torch.cuda.synchronize()
+        ref = R.GBufferRef(W, H)
+        ref.clear()
+        if with_map:
+            mesh.compute_tangents()
+        ref.draw(t, S.draw_params(t, cam.view(), cam.projection(1.0)), diffuse_tex=diffuse.numpy(),
+                 normal_tex=nmap.numpy() if with_map else None)
+        assert (ref.id[..., 0] == 3).sum() > 5000
+        assert np.array_equal(gb.normal_depth.cpu().numpy().view(np.uint16), ref.normal_depth)
+        assert np.array_equal(gb.id.cpu().numpy(), ref.id)
+        assert np.array_equal(gb.canny.cpu().numpy(), ref.canny)
+        assert np.array_equal(gb.color.cpu().numpy().view(np.uint16), ref.color)
+        return ref
+    # NORMAL mode: the mapped normal lands in the normal+depth plane
+    assert not np.array_equal(render(True, 0).normal_depth, render(False, 0).normal_depth)
+    # BAKING mode keeps normal+depth of the snapshot but the corr-map index (id plane) follows the mapped normal
+    assert not np.array_equal(render(True, 2).id[..., 2], render(False, 2).id[..., 2])
