@@ -287,6 +287,24 @@ int sr_legacy_overlap(const float* x, float* y, const int32_t* pix_vert, const i
                       int32_t w, int32_t H, int32_t W, float alpha, int32_t radius, int32_t algo, int32_t keep_nonzero,
                       void* stream);
 
+/* The same legacy Overlap in the REFERENCE'S IN-PLACE ORDER, needed when the kernel radius is > 0: the reference writes into a tensor
+ * that aliases its source (overlap.py:103 `.detach()`), so a vertex sees the updates of the vertices before it (dict order)
+ * through its diagonal pooling windows.
+ *   sr_legacy_levels (HOST arrays in and out): sorts the vertices into conflict-free levels; `order` = vertex indices in dict order
+ *     (first occurrence in (frame, y, x) scan order); level_of[v] = -1 for vertices seen once (they never write).
+ *   sr_legacy_overlap_seq: U (T,C,H,W) fp32 at corr-map resolution is updated in place, level by level (lvl_vert = DEVICE vertex
+ *     indices grouped by level, lvl_off_host = HOST prefix offsets of the groups, max_len = longest trace); newval: scratch of
+ *     (#trace entries x C) floats.
+ *   sr_nearest_resize: F.interpolate(mode="nearest") between latent and corr-map size; with keep_if_zero (same shape as dst) a zero
+ *     result keeps that tensor's value: ResizeOverlap's where(ovlp != 0, ovlp, orig) (overlap.py:180-222). */
+int sr_legacy_levels(const int32_t* offsets, const int32_t* tr_f, const int32_t* tr_y, const int32_t* tr_x, const int32_t* order,
+                     int32_t n_vertices, int32_t T, int32_t H, int32_t W, int32_t radius, int32_t* level_of, int32_t* n_levels);
+int sr_legacy_overlap_seq(float* U, float* newval, const int32_t* lvl_vert, const int32_t* lvl_off_host, int32_t n_levels, int32_t max_len,
+                          const int32_t* offsets, const int32_t* tr_f, const int32_t* tr_y, const int32_t* tr_x, const float* view_normal,
+                          int32_t C, int32_t H, int32_t W, float alpha, int32_t radius, int32_t algo, void* stream);
+int sr_nearest_resize(const float* src, float* dst, int64_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                      const float* keep_if_zero, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Software rasterizer for the G-buffer pass (engine/shaders/default_Gbuffer.{vert,frag}.glsl,
  * engine/managers/renderManager.py:499-571).  One call = one draw task (mesh x material). */
@@ -320,6 +338,16 @@ typedef struct {
   int32_t W, H;
 } sr_gbuffer;
 int sr_gbuffer_clear(const sr_gbuffer* g, void* stream);
+/* identical-G-buffer tasks (RenderManager.AddIdenticalGBufferTask / _wrapIdenticalGBufferTask save_to_temp,
+ * engine/managers/renderManager.py:95-133, 709-733): an object drawn ALONE into `src` is merged into the accumulated planes `acc`
+ * wherever its depth (normal_depth.a, closer = larger) is greater; all seven planes of the winning pixel move together. */
+int sr_gbuffer_depth_merge(const sr_gbuffer* acc, const sr_gbuffer* src, void* stream);
+/* the display image: defer pass (engine/shaders/default_defer_render.frag.glsl:20-59: baking-mode rainbow tint of AI-object ids)
+ * followed by the post process (default_post_process.frag.glsl:21-39: gamma, exposure, saturation, brightness, contrast, HDR).
+ * color RGBA16F (H,W,4), ids (H,W,4) int32 (may be NULL unless is_baking), out RGBA fp32 (H,W,4). */
+int sr_defer_post(const void* color_rgba16f, const int32_t* ids, float* out_rgba, int32_t W, int32_t H, int32_t is_baking,
+                  int32_t enable_gamma, int32_t enable_hdr, float gamma, float exposure, float saturation, float brightness,
+                  float contrast, void* stream);
 /* scratch: see sr_raster_scratch_bytes(nt, W, H) */
 int sr_raster_draw(const sr_draw* d, const sr_gbuffer* g, void* scratch, int64_t scratch_bytes, void* stream);
 int64_t sr_raster_scratch_bytes(int32_t nt, int32_t W, int32_t H);

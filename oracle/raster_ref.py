@@ -85,3 +85,48 @@ class GBufferRef:
             d.tangent, d.bitangent = _np(m.tangents), _np(m.bitangents)
         lib().ref_raster_draw(C.byref(d), C.byref(self.c))
         del keep
+
+
+def depth_merge(acc, src):
+    """identical-G-buffer merge (renderManager.py:118-133) on two GBufferRef: planes of src win where its fp16 depth is greater"""
+    d_src = src.normal_depth[..., 3].view(np.float16).astype(np.float32)
+    d_acc = acc.normal_depth[..., 3].view(np.float16).astype(np.float32)
+    closer = d_src > d_acc
+    for name in ("color", "id", "pos", "normal_depth", "noise", "canny", "zbuf"):
+        getattr(acc, name)[closer] = getattr(src, name)[closer]
+    return closer
+
+
+def defer_post(color_u16, ids, is_baking=False, gamma_on=False, hdr_on=False, gamma=1.0, exposure=1.0, saturation=1.0,
+               brightness=1.0, contrast=1.0):
+    """default_defer_render.frag.glsl:20-59 + default_post_process.frag.glsl:21-39 in numpy fp32 -> (H, W, 4)"""
+    f = np.float32
+    c = color_u16.view(np.float16).astype(f)
+    rgb, a = c[..., :3].copy(), c[..., 3].copy()
+    if is_baking:
+        i = ids.astype(np.int64)
+        obj = (i.sum(-1) > 0) & (i[..., 2] != 2048)
+        ratio = f(1.0) - np.clip(i[..., 3].astype(f) / f(512 * 512), f(0), f(1))
+        col = np.ones(ratio.shape + (3,), f)
+        six = f(6.0)
+        seg = [ratio < f(1.0) / six, ratio < f(2.0) / six, ratio < f(3.0) / six, ratio < f(4.0) / six, ratio < f(5.0) / six]
+        z, o = np.zeros_like(ratio), np.ones_like(ratio)
+        opts = [np.stack([o, ratio * six, z], -1), np.stack([o - (ratio - f(1.0) / six) * six, o, z], -1),
+                np.stack([z, o, (ratio - f(2.0) / six) * six], -1), np.stack([z, o - (ratio - f(3.0) / six) * six, o], -1),
+                np.stack([(ratio - f(4.0) / six) * six, z, o], -1), np.stack([o, z, o - (ratio - f(5.0) / six) * six], -1)]
+        col = opts[5]
+        for k in (4, 3, 2, 1, 0):
+            col = np.where(seg[k][..., None], opts[k], col)
+        mixed = rgb * (f(1.0) - f(0.1)) + col * f(0.1)
+        rgb = np.where(obj[..., None], mixed, rgb)
+        a = np.where(obj, f(1.0), a)
+    v = rgb
+    if gamma_on:
+        v = np.power(v, f(1.0) / f(gamma), dtype=f)
+    v = v * f(exposure)
+    v = f(0.5) * (f(1.0) - f(saturation)) + v * f(saturation)
+    v = v * f(brightness)
+    v = (v - f(0.5)) * f(contrast) + f(0.5)
+    if hdr_on:
+        v = v / (v + f(1.0))
+    return np.concatenate([v.astype(f), a[..., None].astype(f)], -1)

@@ -126,10 +126,15 @@ SYMBOLS = {
     "sr_overlap_csr": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sr_overlap_step": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
     "sr_legacy_overlap": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, vp]),
+    "sr_legacy_levels": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "sr_legacy_overlap_seq": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),
+    "sr_nearest_resize": (C.c_int, [vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     "sr_adain": (C.c_int, [vp, i64, i64, i64, i32, vp, i32, i64, i64, i64, i32, vp, i32, i32, f32, vp, vp]),
     "sr_noise_pool": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "sr_corrmap_update": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
     "sr_gbuffer_clear": (C.c_int, [P(GBuffer), vp]),
+    "sr_gbuffer_depth_merge": (C.c_int, [P(GBuffer), P(GBuffer), vp]),
+    "sr_defer_post": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, f32, f32, vp]),
     "sr_raster_draw": (C.c_int, [P(Draw), P(GBuffer), vp, i64, vp]),
     "sr_raster_scratch_bytes": (i64, [i32, i32, i32]),
 }

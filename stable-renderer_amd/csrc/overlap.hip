@@ -369,6 +369,73 @@ __global__ void legacy_overlap_kernel(const float* __restrict__ x, float* __rest
 
 inline dim3 g1(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
+// ---- legacy Overlap in the REFERENCE'S IN-PLACE ORDER (kernel radius > 0) --------------------------------------------------------
+// The reference walks its vertex dict and writes into a tensor that aliases the one it reads (overlap.py:103 `.detach()`), so a
+// vertex sees the updates of every vertex before it wherever its (2r+1)-pixel diagonal windows touch their pixels.  The host sorts
+// the vertices into LEVELS (sr_legacy_levels): two vertices of one level neither read what the other writes nor write what the
+// other reads, and every conflict with an earlier vertex puts the later one in a later level -- replaying the levels in order,
+// compute-then-write inside each, gives bit for bit what the sequential loop gives.
+__global__ void legacy_seq_compute(const float* __restrict__ U, const int* __restrict__ lvl_vert, int nlv, const int* __restrict__ offsets,
+                                   const int* __restrict__ tr_f, const int* __restrict__ tr_y, const int* __restrict__ tr_x,
+                                   const float* __restrict__ vn, int C, int H, int W, float alpha, int radius, int algo,
+                                   float* __restrict__ newval, int max_len) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int vi = (int)(gid / max_len), t = (int)(gid % max_len);
+  if (vi >= nlv) return;
+  const int v = lvl_vert[vi];
+  const int b = offsets[v], e = offsets[v + 1];
+  if (b + t >= e) return;
+  const int64_t hw = (int64_t)H * W;
+  const int f = tr_f[b + t], y = tr_y[b + t], x = tr_x[b + t];
+  const float inv_r = (float)(2 * radius + 1);
+  float acc[8], norm = 0.f;
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  const float my_vn = (algo == 3) ? vn[((int64_t)f * H + y) * W + x] : 0.f;
+  for (int s = b; s < e; ++s) {
+    const int sf = tr_f[s], sy = tr_y[s], sx = tr_x[s];
+    float wgt;
+    if (algo == 0) wgt = 1.0f;
+    else if (algo == 1) wgt = 1.0f / (fabsf((float)f - (float)sf) + 1.0f);
+    else if (algo == 2) wgt = 1.0f / (fabsf((float)x - (float)sx) + fabsf((float)y - (float)sy) + 1.0f);
+    else wgt = 1.0f / (fabsf(1.0f - vn[((int64_t)sf * H + sy) * W + sx]) + 1.0f);
+    norm += (algo == 3) ? 0.f : wgt;
+    const float* us = U + (int64_t)sf * C * hw;
+    for (int c = 0; c < C; ++c) {
+      float pooled = 0.f;
+      for (int k = -radius; k <= radius; ++k)
+        pooled += us[c * hw + (int64_t)min(max(sy + k, 0), H - 1) * W + min(max(sx + k, 0), W - 1)];
+      acc[c] += wgt * (pooled / inv_r);
+    }
+  }
+  if (algo == 3) norm = (float)(e - b) * (1.0f / (fabsf(1.0f - my_vn) + 1.0f));
+  const float* uf = U + (int64_t)f * C * hw + (int64_t)y * W + x;
+  for (int c = 0; c < C; ++c) newval[(int64_t)(b + t) * C + c] = alpha * (acc[c] / norm) + (1.0f - alpha) * uf[c * hw];
+}
+__global__ void legacy_seq_write(float* __restrict__ U, const int* __restrict__ lvl_vert, int nlv, const int* __restrict__ offsets,
+                                 const int* __restrict__ tr_f, const int* __restrict__ tr_y, const int* __restrict__ tr_x, int C, int H,
+                                 int W, const float* __restrict__ newval, int max_len) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int vi = (int)(gid / max_len), t = (int)(gid % max_len);
+  if (vi >= nlv) return;
+  const int v = lvl_vert[vi];
+  const int b = offsets[v], e = offsets[v + 1];
+  if (b + t >= e) return;
+  const int64_t hw = (int64_t)H * W;
+  float* uf = U + (int64_t)tr_f[b + t] * C * hw + (int64_t)tr_y[b + t] * W + tr_x[b + t];
+  for (int c = 0; c < C; ++c) uf[c * hw] = newval[(int64_t)(b + t) * C + c];
+}
+// F.interpolate(mode="nearest"): dst (T,C,Ho,Wo) <- src (T,C,Hi,Wi), src index = min(floor(dst * in/out), in-1) (fp32 scale)
+__global__ void nearest_resize_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t planes, int Hi, int Wi, int Ho, int Wo,
+                                      const float* __restrict__ keep_if_zero) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= planes * Ho * Wo) return;
+  const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+  const int64_t pl = i / ((int64_t)Wo * Ho);
+  const int yi = min((int)floorf((float)yo * ((float)Hi / (float)Ho)), Hi - 1), xi = min((int)floorf((float)xo * ((float)Wi / (float)Wo)), Wi - 1);
+  const float v = src[(pl * Hi + yi) * Wi + xi];
+  dst[i] = (keep_if_zero && v == 0.0f) ? keep_if_zero[i] : v;      // ResizeOverlap: where(ovlp != 0, ovlp, orig) (overlap.py:218-221)
+}
+
 }  // namespace
 
 extern "C" int sr_legacy_overlap(const float* x, float* y, const int32_t* pix_vert, const int32_t* offsets, const int32_t* tr_f,
@@ -380,6 +447,33 @@ extern "C" int sr_legacy_overlap(const float* x, float* y, const int32_t* pix_ve
   hipLaunchKernelGGL(legacy_overlap_kernel, g1((int64_t)T * h * w), dim3(256), 0, sr_stream(stream), x, y, pix_vert, offsets, tr_f, tr_y, tr_x,
                      view_normal, T, C, h, w, H, W, alpha, radius, algo, keep_nonzero);
   SR_CHECK_LAUNCH("sr_legacy_overlap");
+  return SR_OK;
+}
+
+extern "C" int sr_legacy_overlap_seq(float* U, float* newval, const int32_t* lvl_vert, const int32_t* lvl_off_host, int32_t n_levels,
+                                     int32_t max_len, const int32_t* offsets, const int32_t* tr_f, const int32_t* tr_y, const int32_t* tr_x,
+                                     const float* view_normal, int32_t C, int32_t H, int32_t W, float alpha, int32_t radius, int32_t algo,
+                                     void* stream) {
+  if (!U || !newval || !lvl_vert || !lvl_off_host || !offsets || !tr_f || !tr_y || !tr_x) SR_FAIL(SR_ERR_INVALID, "sr_legacy_overlap_seq: null");
+  if (C > 8 || radius < 0 || algo < 0 || algo > 3 || (algo == 3 && !view_normal) || max_len < 1) SR_FAIL(SR_ERR_INVALID, "sr_legacy_overlap_seq: bad args");
+  hipStream_t st = sr_stream(stream);
+  for (int l = 0; l < n_levels; ++l) {
+    const int b = lvl_off_host[l], n = lvl_off_host[l + 1] - b;
+    if (n <= 0) continue;
+    const dim3 grid = g1((int64_t)n * max_len);
+    hipLaunchKernelGGL(legacy_seq_compute, grid, dim3(256), 0, st, U, lvl_vert + b, n, offsets, tr_f, tr_y, tr_x, view_normal, C, H, W, alpha,
+                       radius, algo, newval, max_len);
+    hipLaunchKernelGGL(legacy_seq_write, grid, dim3(256), 0, st, U, lvl_vert + b, n, offsets, tr_f, tr_y, tr_x, C, H, W, newval, max_len);
+  }
+  SR_CHECK_LAUNCH("sr_legacy_overlap_seq");
+  return SR_OK;
+}
+
+extern "C" int sr_nearest_resize(const float* src, float* dst, int64_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                 const float* keep_if_zero, void* stream) {
+  if (!src || !dst || planes < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) SR_FAIL(SR_ERR_INVALID, "sr_nearest_resize: bad args");
+  hipLaunchKernelGGL(nearest_resize_kernel, g1(planes * Ho * Wo), dim3(256), 0, sr_stream(stream), src, dst, planes, Hi, Wi, Ho, Wo, keep_if_zero);
+  SR_CHECK_LAUNCH("sr_nearest_resize");
   return SR_OK;
 }
 

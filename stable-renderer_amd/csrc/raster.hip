@@ -397,6 +397,84 @@ __global__ void gbuffer_clear_kernel(const sr_gbuffer g) {
 
 extern "C" int64_t sr_raster_scratch_bytes(int32_t nt, int32_t, int32_t) { return (int64_t)nt * (int64_t)sizeof(TriRec); }
 
+// ---- identical-G-buffer merge (renderManager.py:118-133): an object drawn ALONE into a cleared G-buffer is folded into the
+// accumulated planes wherever its depth (normal_depth.a = 1 - window z: closer = larger, compared in fp16 as stored) beats theirs
+__global__ void gbuffer_depth_merge_kernel(sr_gbuffer acc, const sr_gbuffer src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ushort4 s_nd = ((const ushort4*)src.normal_depth)[i];
+  const ushort4 a_nd = ((const ushort4*)acc.normal_depth)[i];
+  if (!(h2f(s_nd.w) > h2f(a_nd.w))) return;
+  ((ushort4*)acc.normal_depth)[i] = s_nd;
+  ((ushort4*)acc.color)[i] = ((const ushort4*)src.color)[i];
+  ((int4*)acc.id)[i] = ((const int4*)src.id)[i];
+  ((ushort4*)acc.noise)[i] = ((const ushort4*)src.noise)[i];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { acc.pos[(size_t)i * 3 + k] = src.pos[(size_t)i * 3 + k]; acc.canny[(size_t)i * 3 + k] = src.canny[(size_t)i * 3 + k]; }
+  if (acc.zbuf && src.zbuf) acc.zbuf[i] = src.zbuf[i];
+}
+
+// ---- defer pass + post process (default_defer_render.frag.glsl:20-59, default_post_process.frag.glsl:21-39): the display image.
+// Baking: AI-object pixels (any id set, map_index != 2048) are tinted 10 % with a rainbow of the vertex id; then gamma, exposure,
+// saturation, brightness, contrast, optional HDR tone map.  out RGBA fp32.
+__global__ void defer_post_kernel(const uint16_t* __restrict__ color, const int32_t* __restrict__ ids, float* __restrict__ out, int n,
+                                  int is_baking, int gamma_on, int hdr_on, float gamma, float exposure, float saturation,
+                                  float brightness, float contrast) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ushort4 c = ((const ushort4*)color)[i];
+  float rgb[3] = {h2f(c.x), h2f(c.y), h2f(c.z)};
+  float a = h2f(c.w);
+  if (is_baking) {
+    const int4 id = ((const int4*)ids)[i];
+    if (id.x + id.y + id.z + id.w > 0 && id.z != NON_AI_OBJ_MAP_INDEX) {
+      float ratio = (float)id.w / (float)(512 * 512);
+      ratio = 1.0f - fminf(fmaxf(ratio, 0.0f), 1.0f);
+      float col[3] = {1.0f, 1.0f, 1.0f};
+      if (ratio < 1.0f / 6.0f) { col[0] = 1.0f; col[1] = ratio * 6.0f; col[2] = 0.0f; }
+      else if (ratio < 2.0f / 6.0f) { col[0] = 1.0f - (ratio - 1.0f / 6.0f) * 6.0f; col[1] = 1.0f; col[2] = 0.0f; }
+      else if (ratio < 3.0f / 6.0f) { col[0] = 0.0f; col[1] = 1.0f; col[2] = (ratio - 2.0f / 6.0f) * 6.0f; }
+      else if (ratio < 4.0f / 6.0f) { col[0] = 0.0f; col[1] = 1.0f - (ratio - 3.0f / 6.0f) * 6.0f; col[2] = 1.0f; }
+      else if (ratio < 5.0f / 6.0f) { col[0] = (ratio - 4.0f / 6.0f) * 6.0f; col[1] = 0.0f; col[2] = 1.0f; }
+      else { col[0] = 1.0f; col[1] = 0.0f; col[2] = 1.0f - (ratio - 5.0f / 6.0f) * 6.0f; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rgb[k] = rgb[k] * (1.0f - 0.1f) + col[k] * 0.1f;      // mix(FragColor.rgb, col, 0.1)
+      a = 1.0f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = rgb[k];
+    if (gamma_on) v = powf(v, 1.0f / gamma);
+    v = v * exposure;
+    v = 0.5f * (1.0f - saturation) + v * saturation;                                     // mix(vec3(0.5), rgb, saturation)
+    v = v * brightness;
+    v = (v - 0.5f) * contrast + 0.5f;
+    if (hdr_on) v = v / (v + 1.0f);
+    out[(size_t)i * 4 + k] = v;
+  }
+  out[(size_t)i * 4 + 3] = a;
+}
+
+extern "C" int sr_gbuffer_depth_merge(const sr_gbuffer* acc, const sr_gbuffer* src, void* stream) {
+  if (!acc || !src || acc->W != src->W || acc->H != src->H) SR_FAIL(SR_ERR_INVALID, "sr_gbuffer_depth_merge: bad args");
+  const int n = acc->W * acc->H;
+  hipLaunchKernelGGL(gbuffer_depth_merge_kernel, dim3((n + 255) / 256), dim3(256), 0, sr_stream(stream), *acc, *src, n);
+  SR_CHECK_LAUNCH("sr_gbuffer_depth_merge");
+  return SR_OK;
+}
+
+extern "C" int sr_defer_post(const void* color_rgba16f, const int32_t* ids, float* out_rgba, int32_t W, int32_t H, int32_t is_baking,
+                             int32_t enable_gamma, int32_t enable_hdr, float gamma, float exposure, float saturation, float brightness,
+                             float contrast, void* stream) {
+  if (!color_rgba16f || !out_rgba || (is_baking && !ids) || W < 1 || H < 1) SR_FAIL(SR_ERR_INVALID, "sr_defer_post: bad args");
+  const int n = W * H;
+  hipLaunchKernelGGL(defer_post_kernel, dim3((n + 255) / 256), dim3(256), 0, sr_stream(stream), (const uint16_t*)color_rgba16f, ids, out_rgba,
+                     n, is_baking, enable_gamma, enable_hdr, gamma, exposure, saturation, brightness, contrast);
+  SR_CHECK_LAUNCH("sr_defer_post");
+  return SR_OK;
+}
+
 extern "C" int sr_gbuffer_clear(const sr_gbuffer* g, void* stream) {
   if (!g || !g->color || !g->id || !g->pos || !g->normal_depth || !g->noise || !g->canny || !g->zbuf) SR_FAIL(SR_ERR_INVALID, "sr_gbuffer_clear: null plane");
   const size_t n = (size_t)g->W * g->H;

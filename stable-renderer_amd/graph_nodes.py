@@ -406,6 +406,11 @@ for _name, _cls in (("CheckpointLoaderSimple", CheckpointLoaderSimple), ("LoraLo
                     ("ImageSequenceLoader", N.ImageSequenceLoader), ("NoiseSequenceLoader", N.NoiseSequenceLoader)):
     register_node(_name, _cls)
 
+from . import extra_nodes as _X  # noqa: E402
+
+for _name, _cls in _X.ALL.items():
+    register_node(_name, _cls)
+
 
 def register_legacy_aliases():
     """opt-in: node names of earlier reference revisions that shipped example graphs still use (see nodes.FrameDataNode)"""

@@ -1,7 +1,9 @@
 """Legacy "latent overlapping" (the dict-based CorrespondenceMap path of legacy_codes/stable_rendering_algo), same class
 names and call contract: ``Scheduler`` (overlap/overlap_scheduler.py:8-106), the four ``OverlapAlgorithm``s
 (overlap/algorithms.py:34-118), ``Overlap`` / ``ResizeOverlap`` (overlap/overlap.py:18-222).  The per-vertex Python loop of the
-reference becomes one HIP kernel (``sr_legacy_overlap``) over a CSR of vertex traces built once per id-map batch."""
+reference becomes one HIP kernel (``sr_legacy_overlap``) over a CSR of vertex traces built once per id-map batch; with a kernel
+radius > 0, where the reference's in-place update order is observable, the vertices are replayed in conflict-free levels of that
+order (``sr_legacy_levels`` + ``sr_legacy_overlap_seq``) on a corr-map-resolution working tensor."""
 import math
 
 import torch
@@ -80,6 +82,32 @@ class CorrespondenceMap:
         self.tr_f = (pix // (H * W)).to(torch.int32).contiguous()
         self.tr_y = ((pix // W) % H).to(torch.int32).contiguous()
         self.tr_x = (pix % W).to(torch.int32).contiguous()
+        # the reference's dict order = order of first appearance in the (frame, y, x) scan (correspondence_map.py:150-166):
+        # what the in-place update order of Overlap.__call__ follows (kernel radius > 0)
+        first = torch.full((max(self.n_vertices, 1),), T * H * W, dtype=torch.int64, device=ids.device)
+        first.scatter_reduce_(0, vert[pix], pix, reduce="amin")
+        self.order = torch.argsort(first[:self.n_vertices], stable=True).to(torch.int32)
+        self.max_len = int(counts.max()) if self.n_vertices else 1
+        self._levels = {}
+
+    def levels(self, radius):
+        """-> (lvl_vert device int32: multi-pixel vertices grouped by level, lvl_off host int32 prefix offsets, n_levels) for the
+        in-place order at this kernel radius (sr_legacy_levels; built once per radius)"""
+        import ctypes as C
+        import numpy as np
+        if radius not in self._levels:
+            off, f, y, x, order = (t.cpu().numpy() for t in (self.offsets, self.tr_f, self.tr_y, self.tr_x, self.order))
+            lvl = np.empty(max(self.n_vertices, 1), np.int32)
+            nl = C.c_int32(0)
+            ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+            L.check(L.lib().sr_legacy_levels(ptr(off), ptr(f), ptr(y), ptr(x), ptr(order), self.n_vertices, self.num_frames, self.height,
+                                             self.width, int(radius), ptr(lvl), C.byref(nl)))
+            lvl = lvl[:self.n_vertices]
+            active = np.nonzero(lvl >= 0)[0]
+            by_level = active[np.argsort(lvl[active], kind="stable")].astype(np.int32)
+            lvl_off = np.concatenate([[0], np.cumsum(np.bincount(lvl[active], minlength=nl.value))]).astype(np.int32)
+            self._levels[radius] = (torch.from_numpy(by_level).to(self.pix_vert.device), lvl_off, int(nl.value))
+        return self._levels[radius]
 
     @property
     def size(self):
@@ -100,6 +128,8 @@ class Overlap:
         T, B, C, h, w = x.shape
         assert B == 1, "the legacy path handles one latent per frame"
         xin = x.reshape(T, C, h, w).contiguous().float()
+        if radius > 0:
+            return self._run_in_place_order(xin, corr_map, alpha, radius, view_normal_map).reshape(T, 1, C, h, w)
         y = torch.empty_like(xin)
         vn = None
         if self.algorithm.algo == 3:
@@ -110,6 +140,35 @@ class Overlap:
                                           O._p(corr_map.tr_y), O._p(corr_map.tr_x), O._p(vn), T, C, h, w, corr_map.height, corr_map.width,
                                           float(alpha), int(radius), self.algorithm.algo, self.keep_nonzero, O.stream_ptr()))
         return y.reshape(T, 1, C, h, w)
+
+    def _run_in_place_order(self, xin, corr_map, alpha, radius, view_normal_map):
+        """kernel radius > 0: the reference's in-place update order (overlap.py:103-146), replayed level by level on a
+        corr-map-resolution working tensor (sr_legacy_overlap_seq).  ResizeOverlap: nearest up, overlap, nearest down + where."""
+        import ctypes as C
+        T, Cc, h, w = xin.shape
+        H, W = corr_map.height, corr_map.width
+        lib, st = L.lib(), O.stream_ptr()
+        vn = None
+        if self.algorithm.algo == 3:
+            if view_normal_map is None:
+                raise TypeError("overlap() missing 1 required positional argument: 'view_normal_map'")
+            vn = view_normal_map.reshape(T, H, W).contiguous().float().to(xin.device)
+        if (h, w) == (H, W):
+            U = xin.clone()
+        else:
+            U = torch.empty(T, Cc, H, W, dtype=torch.float32, device=xin.device)
+            L.check(lib.sr_nearest_resize(O._p(xin), O._p(U), T * Cc, h, w, H, W, None, st))
+        lvl_vert, lvl_off, n_levels = corr_map.levels(radius)
+        if n_levels > 0:
+            newval = torch.empty(int(corr_map.offsets[-1]) * Cc, dtype=torch.float32, device=xin.device)
+            L.check(lib.sr_legacy_overlap_seq(O._p(U), O._p(newval), O._p(lvl_vert), lvl_off.ctypes.data_as(C.c_void_p), n_levels,
+                                              corr_map.max_len, O._p(corr_map.offsets), O._p(corr_map.tr_f), O._p(corr_map.tr_y),
+                                              O._p(corr_map.tr_x), O._p(vn), Cc, H, W, float(alpha), int(radius), self.algorithm.algo, st))
+        if (h, w) == (H, W):
+            return U
+        y = torch.empty_like(xin)
+        L.check(lib.sr_nearest_resize(O._p(U), O._p(y), T * Cc, H, W, h, w, O._p(xin) if self.keep_nonzero else None, st))
+        return y
 
     def __call__(self, frame_seq, corr_map, step=None, timestep=None, view_normal_map=None, **kwargs):
         assert tuple(frame_seq[0].shape[2:]) == (corr_map.height, corr_map.width), "frame shape does not match corr_map shape"

@@ -353,6 +353,28 @@ class GBuffer:
             self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
         L.check(L.lib().sr_raster_draw(C.byref(d), C.byref(self.c), O._p(self._scratch), self._scratch.numel(), O.stream_ptr()))
 
+    def render_identical(self, tasks, camera, scratch=None):
+        """identical-G-buffer tasks (renderManager.py:95-133, 954-959): every task is drawn ALONE into a cleared scratch G-buffer
+        and merged into this one by depth, so each object's planes come out as if nothing occluded it except closer objects'
+        whole-pixel wins; ``self`` must have been cleared (or hold earlier merges)"""
+        view, proj = camera.view(), camera.projection(self.W / self.H)
+        tmp = scratch if scratch is not None else GBuffer(self.W, self.H, device=self.color.device)
+        for t in sorted(tasks, key=lambda t: t.order):
+            tmp.clear()
+            tmp.draw(t, view, proj)
+            L.check(L.lib().sr_gbuffer_depth_merge(C.byref(self.c), C.byref(tmp.c), O.stream_ptr()))
+        return tmp
+
+    def display(self, is_baking=False, enableGammaCorrection=False, enableHDR=False, gamma=1.0, exposure=1.0, saturation=1.0,
+                brightness=1.0, contrast=1.0):
+        """defer render + post process (default_defer_render / default_post_process shaders; Engine kwargs enableHDR,
+        enableGammaCorrection, gamma, exposure, saturation, brightness, contrast, engine.py:76-92) -> (H, W, 4) fp32 RGBA"""
+        out = torch.empty(self.H, self.W, 4, dtype=torch.float32, device=self.color.device)
+        L.check(L.lib().sr_defer_post(O._p(self.color), O._p(self.id), O._p(out), self.W, self.H, int(is_baking),
+                                      int(enableGammaCorrection), int(enableHDR), float(gamma), float(exposure), float(saturation),
+                                      float(brightness), float(contrast), O.stream_ptr()))
+        return out
+
     def render(self, tasks, camera):
         """RenderManager.on_frame_run's G-buffer part: clear, tasks sorted by order (stable), depth test off for the
         TRANSPARENT queue (renderManager.py:508-513)."""

@@ -117,8 +117,8 @@ def test_corrmap_dump_load_interchange(tmp_path):
 
 
 def test_legacy_overlap_vs_reference():
-    """legacy Overlap / ResizeOverlap: radius 0 against the REFERENCE's outputs for all four algorithms; radius 1 against
-    the oracle's order-independent (Jacobi) form (the reference's in-place update order is not parallelisable)."""
+    """legacy Overlap / ResizeOverlap against the REFERENCE's outputs for all four algorithms: kernel radius 0, and radius 1 where
+    the reference's in-place update order matters (replayed in conflict-free levels of its dict order)"""
     import sr_oracle as ORC
     from stable_renderer_amd import legacy_overlap as LO
     d = np.load(os.path.join(GOLD, "legacy_overlap.npz"))
@@ -135,12 +135,17 @@ def test_legacy_overlap_vs_reference():
             kw = dict(alpha_scheduler=LO.Scheduler(interpolate_begin=0.6), kernel_radius_scheduler=LO.Scheduler(interpolate_begin=float(r)), algorithm=a)
             full = LO.Overlap(**kw)(frames, cm, step=1, timestep=500, view_normal_map=vn).cpu().numpy()
             rs = torch.stack(LO.ResizeOverlap(**kw)(lat, cm, step=1, timestep=500, view_normal_map=vn)).cpu().numpy()
-            if r == 0:
-                assert np.allclose(full, d[f"full_{name}_r0"], atol=2e-5, rtol=1e-5), name
-                assert np.allclose(rs, d[f"resize_{name}_r0"], atol=2e-5, rtol=1e-5), name
-            else:
-                assert np.allclose(full, ORC.legacy_overlap(d["frames"], d["ids"], 0.6, 1, name, d["view_normal"], sequential=False), atol=2e-5), name
-                assert np.allclose(rs, ORC.legacy_resize_overlap(d["latents"], d["ids"], 0.6, 1, name, d["view_normal"], sequential=False), atol=2e-5), name
+            assert np.allclose(full, d[f"full_{name}_r{r}"], atol=2e-5, rtol=1e-5), (name, r, np.abs(full - d[f"full_{name}_r{r}"]).max())
+            assert np.allclose(rs, d[f"resize_{name}_r{r}"], atol=2e-5, rtol=1e-5), (name, r)
+            if r == 1:                                        # the in-place order is observable: the Jacobi form differs
+                jac = ORC.legacy_overlap(d["frames"], d["ids"], 0.6, 1, name, d["view_normal"], sequential=False)
+                assert not np.allclose(jac, d[f"full_{name}_r1"], atol=1e-4), name
+    # a larger radius: in-place order vs the oracle's sequential loop (itself pinned to the reference at r = 0, 1)
+    kw = dict(alpha_scheduler=LO.Scheduler(interpolate_begin=0.45), kernel_radius_scheduler=LO.Scheduler(interpolate_begin=3.0), algorithm=algos["pixel"])
+    full = LO.Overlap(**kw)(frames, cm, step=1, timestep=500).cpu().numpy()
+    assert np.allclose(full, ORC.legacy_overlap(d["frames"], d["ids"], 0.45, 3, "pixel", None, sequential=True), atol=2e-5)
+    lv, off, nl = cm.levels(3)
+    assert nl > 1 and int(off[-1]) == len(lv)
     # alpha == 0 returns the input list untouched (overlap.py:203-204)
     z = LO.ResizeOverlap(LO.Scheduler(interpolate_begin=0.0), LO.Scheduler(), LO.AverageDistance())
     assert z(lat, cm, step=1, timestep=500) is lat

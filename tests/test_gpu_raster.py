@@ -188,3 +188,53 @@ def test_normal_map_tbn_branch_bit_exact():
     assert not np.array_equal(render(True, 0).normal_depth, render(False, 0).normal_depth)
     # BAKING mode keeps normal+depth of the snapshot but the corr-map index (id plane) follows the mapped normal
     assert not np.array_equal(render(True, 2).id[..., 2], render(False, 2).id[..., 2])
+
+
+def test_identical_gbuffer_merge_and_display_pass():
+    """AddIdenticalGBufferTask semantics (each object alone, merged by depth, renderManager.py:95-133) and the defer + post-process
+    display pass (default_defer_render / default_post_process shaders) against their numpy restatements"""
+    import raster_ref as R
+    from stable_renderer_amd import scene as S
+    W = H = 160
+    cam, tasks = _scene(W, H, 3)
+    tasks = tasks[:2]                                           # the vertex-coloured plane and the textured sphere
+    gb = S.GBuffer(W, H)
+    gb.clear()
+    gb.render_identical(tasks, cam)
+    torch.cuda.synchronize()
+    view, proj = cam.view(), cam.projection(1.0)
+    acc = R.GBufferRef(W, H)
+    acc.clear()
+    acc.zbuf[:] = 1.0
+    for t in sorted(tasks, key=lambda t: t.order):
+        one = R.GBufferRef(W, H)
+        one.clear()
+        one.draw(t, S.draw_params(t, view, proj),
+                 noise_tex=None if t.noise_tex is None else t.noise_tex.numpy().view(np.uint16),
+                 diffuse_tex=None if t.diffuse_tex is None else t.diffuse_tex.numpy())
+        won = R.depth_merge(acc, one)
+        assert won.any()
+    assert np.array_equal(gb.id.cpu().numpy(), acc.id)
+    assert np.array_equal(gb.color.cpu().numpy().view(np.uint16), acc.color)
+    assert np.array_equal(gb.normal_depth.cpu().numpy().view(np.uint16), acc.normal_depth)
+    assert np.array_equal(gb.pos.cpu().numpy().view(np.uint32), acc.pos.view(np.uint32))
+    assert (acc.id[..., 0] == 1).any() and (acc.id[..., 0] == 3).any()
+    # display pass on a baking frame: rainbow tint of AI ids + post process
+    cam, tasks = _scene(W, H, 3)
+    gb.render(tasks, cam)
+    ref = R.GBufferRef(W, H)
+    ref.clear()
+    for t in sorted(tasks, key=lambda t: t.order):
+        ref.draw(t, S.draw_params(t, view, proj),
+                 noise_tex=None if t.noise_tex is None else t.noise_tex.numpy().view(np.uint16),
+                 diffuse_tex=None if t.diffuse_tex is None else t.diffuse_tex.numpy())
+    for kw in (dict(is_baking=True), dict(is_baking=False, enableGammaCorrection=True, gamma=2.2, exposure=1.3, saturation=0.8,
+                                           brightness=1.1, contrast=1.2, enableHDR=True)):
+        img = gb.display(**kw).cpu().numpy()
+        want = R.defer_post(ref.color, ref.id, is_baking=kw.get("is_baking", False), gamma_on=kw.get("enableGammaCorrection", False),
+                            hdr_on=kw.get("enableHDR", False), gamma=kw.get("gamma", 1.0), exposure=kw.get("exposure", 1.0),
+                            saturation=kw.get("saturation", 1.0), brightness=kw.get("brightness", 1.0), contrast=kw.get("contrast", 1.0))
+        assert np.allclose(img, want, atol=2e-6, rtol=1e-5), np.abs(img - want).max()
+    tinted = gb.display(is_baking=True).cpu().numpy()
+    plain = gb.display(is_baking=False).cpu().numpy()
+    assert (np.abs(tinted - plain).max(-1) > 0.01).sum() > 1000
