@@ -1,0 +1,35 @@
+"""HBM-side traffic of the igemm family per UNet evaluation from the two PMC passes of tools/profile_round.sh (development tool).
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch; on gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes
+(MI355X_MICROARCH.md, HBM section): doubled here.  `bench.py --roofline-only` makes 7 replays of the igemm subset + 5 of the whole
+step plan = 12 evaluations' worth of igemm launches (plus one eager plan run at load: 13)."""
+import csv
+import glob
+import json
+import sys
+
+out = sys.argv[1]
+FAMILY = ("igemm_kernel", "conv3p_kernel", "splitk_reduce_kernel")
+
+
+def total(kind):
+    s, n = 0.0, 0
+    for f in glob.glob(f"{out}/{kind}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if any(k in r["Kernel_Name"] for k in FAMILY):
+                s += float(r["Counter_Value"])
+                n += 1
+    return s, n
+
+
+fetch_kb, nf = total("fetch")
+write_kb, nw = total("write")
+launches_per_eval = 229
+evals = nf / launches_per_eval if nf else 0
+res = {"fetch_size_kb_sum": fetch_kb, "write_size_kb_sum": write_kb, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,
+       "evaluations_in_pass": round(evals, 2),
+       "fetch_bytes_per_eval_corrected": None if not evals else 2.0 * fetch_kb * 1024 / evals,
+       "write_bytes_per_eval": None if not evals else write_kb * 1024 / (nw / launches_per_eval),
+       "note": "FETCH_SIZE x2 (gfx950 counts 16-B-per-lane reads at half); igemm family = igemm_kernel tiles + conv3p_kernel + splitk_reduce_kernel"}
+if evals:
+    res["hbm_bytes_per_eval"] = res["fetch_bytes_per_eval_corrected"] + res["write_bytes_per_eval"]
+print(json.dumps(res, indent=1))
