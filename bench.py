@@ -49,6 +49,11 @@ def cpu_baseline():
                       "scaled x4.08 to 512^2; extrapolated per view, overlap step / raster excluded (<0.1%%)" % (t_unet, t_vae256)}
 
 
+# profiles/r02_igemm_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) of the igemm family over the 12 UNet evaluations of
+# `bench.py --roofline-only`, per evaluation
+MEASURED_IGEMM_TRAFFIC_BYTES = 34.85e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +173,9 @@ def main():
                 self.n = sum(p_.n for p_ in self.plans)
                 self.op_flops = [f for p_ in self.plans for f in p_.op_flops]
 
+            def igemm_bytes(self):
+                return sum(p_.igemm_bytes() for p_ in self.plans)
+
             def run(self):
                 for p_ in self.plans:
                     p_.run()
@@ -190,7 +198,12 @@ def main():
         peak = 2500.0 if a.dtype == "f16" else 157.3
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm family: igemm_kernel tiles + conv3p_kernel (implicit-GEMM conv/linear, all %d launches of one UNet eval, B=%d)" % (sub.n, a.views * 2),
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                # HBM-side bytes of these launches per UNet evaluation from the FETCH_SIZE (x2, gfx950) + WRITE_SIZE PMC passes of
+                # this very replay (tools/profile_round.sh -> profiles/r02_igemm_traffic.json); PMC cannot be collected from
+                # inside the process, so the figure is the recorded one and only quoted for the configuration it was measured on
+                "traffic": MEASURED_IGEMM_TRAFFIC_BYTES if (a.dtype == "f16" and a.views == 8 and shard is None and not a.controlnets) else None,
+                "algorithmic_bytes": sub.igemm_bytes(),
                 "launches": sub.n, "avg_launch_us": round(ms * 1e3 / max(sub.n, 1), 2), "flops_per_eval": flops}
         full = pipe.runner._plan["flops"]
         e0.record()

@@ -9,6 +9,18 @@ from . import _lib as L
 from . import ops as O
 
 
+def igemm_algorithmic_bytes(ar):
+    """HBM bytes one igemm launch has to move once: source pixels (both concat sources), packed weights, output
+    (+ residual read); the figure the measured FETCH_SIZE / WRITE_SIZE traffic of a launch is compared with"""
+    es = 2 if ar.dtype == L.SR_F16 else 4
+    st, up = max(ar.stride, 1), ar.upsample
+    Ho, Wo = ((ar.up_h, ar.up_w) if ar.up_h else (2 * ar.H, 2 * ar.W)) if up else ((ar.H + st - 1) // st, (ar.W + st - 1) // st)
+    M, C = ar.B * Ho * Wo, ar.C1 + ar.C2
+    n_out = ar.N // 2 if ar.act == 2 else ar.N
+    return (ar.B * ar.H * ar.W * C * es + ar.N * ar.KH * ar.KH * C * es + M * n_out * (4 if ar.out_f32 else es)
+            + (M * n_out * es if ar.residual else 0))
+
+
 class Plan:
     def __init__(self, op_list, keep, op_flops=None):
         self.op_flops = list(op_flops) if op_flops is not None else [0] * len(op_list)
@@ -20,6 +32,10 @@ class Plan:
 
     def run(self):
         L.check(L.lib().sr_plan_run(self.ops, self.n, O.stream_ptr()))
+
+    def igemm_bytes(self):
+        """sum of igemm_algorithmic_bytes over the plan's igemm ops"""
+        return sum(igemm_algorithmic_bytes(self.ops[i].u.igemm) for i in range(self.n) if self.ops[i].kind == L.OP_IGEMM)
 
     def subset(self, kind):
         """-> Plan holding only the ops of one kind (same buffers), all on the main lane: used to time one kernel family

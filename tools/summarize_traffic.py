@@ -1,7 +1,8 @@
 """HBM-side traffic of the igemm family per UNet evaluation from the two PMC passes of tools/profile_round.sh (development tool).
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch; on gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes
 (MI355X_MICROARCH.md, HBM section): doubled here.  `bench.py --roofline-only` makes 7 replays of the igemm subset + 5 of the whole
-step plan = 12 evaluations' worth of igemm launches (plus one eager plan run at load: 13)."""
+step plan = 12 evaluations' worth of igemm launches (the few extra launches of the same kernels in the prologue plan — cross-attention
+K/V and time-embedding GEMMs, run once per sampling run — are counted in: < 0.5 % of the bytes)."""
 import csv
 import glob
 import json
@@ -23,12 +24,11 @@ def total(kind):
 
 fetch_kb, nf = total("fetch")
 write_kb, nw = total("write")
-launches_per_eval = 229
-evals = nf / launches_per_eval if nf else 0
+evals = 12 if nf else 0          # 7 replays of the igemm subset + 5 of the whole step plan (bench.py --roofline-only)
 res = {"fetch_size_kb_sum": fetch_kb, "write_size_kb_sum": write_kb, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,
-       "evaluations_in_pass": round(evals, 2),
+       "evaluations_in_pass": evals,
        "fetch_bytes_per_eval_corrected": None if not evals else 2.0 * fetch_kb * 1024 / evals,
-       "write_bytes_per_eval": None if not evals else write_kb * 1024 / (nw / launches_per_eval),
+       "write_bytes_per_eval": None if not evals else write_kb * 1024 / evals,
        "note": "FETCH_SIZE x2 (gfx950 counts 16-B-per-lane reads at half); igemm family = igemm_kernel tiles + conv3p_kernel + splitk_reduce_kernel"}
 if evals:
     res["hbm_bytes_per_eval"] = res["fetch_bytes_per_eval_corrected"] + res["write_bytes_per_eval"]
