@@ -381,19 +381,21 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
       for (int st = 0; st < DQ; ++st) qf[qt][st] = __builtin_bit_cast(uint4, __builtin_bit_cast(h16x8, qf[qt][st]) * hsv);
   }
 
-  // ---- per-thread load slots (loop invariant): which K / V^T chunk this thread moves every tile
-  const T* kbase = (const T*)p.k + (int64_t)bk * Tk * p.k_stride + h * d;
-  const T* vbase = (const T*)p.vt + ((int64_t)bk * p.heads + h) * (int64_t)d * p.ldt;
-  int k_key[KPT], k_lds[KPT], k_el[KPT]; bool k_ok[KPT], k_one[KPT];
+  // ---- per-thread load slots (loop invariant): which K / V^T chunk this thread moves every tile.  Sources are a workgroup-uniform
+  // base (SGPR pair) + a 32-bit byte offset per lane: no 64-bit address arithmetic or pointer registers in the loop
+  const char* kbase = (const char*)((const T*)p.k + (int64_t)bk * Tk * p.k_stride + h * d);
+  const char* vbase = (const char*)((const T*)p.vt + ((int64_t)bk * p.heads + h) * (int64_t)d * p.ldt);
+  const unsigned krow_b = (unsigned)p.k_stride * 2u;
+  int k_key[KPT], k_lds[KPT]; unsigned k_boff[KPT]; bool k_ok[KPT], k_one[KPT];
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
     const int idx = tid + i * NTHR, key = idx / NCH, ch = idx - key * NCH;
-    k_key[i] = key; k_el[i] = ch * EPC;
+    k_key[i] = key; k_boff[i] = (unsigned)(ch * EPC) * 2u;
     k_one[i] = LAZY && idx < KV * NCH && ch * EPC == d;     // the shift channel: 1.0 in element 0
     k_ok[i] = idx < KV * NCH && ch * EPC < d;
     k_lds[i] = idx < KV * NCH ? key * KROW + ((NCH == 8) ? (ch ^ (key & 7)) : ch) * 16 : -1;
   }
-  const T* v_src[VPT]; int v_lds[VPT], v_k8[VPT]; bool v_ok[VPT], v_one[VPT];
+  unsigned v_boff[VPT]; int v_lds[VPT], v_k8[VPT]; bool v_ok[VPT], v_one[VPT];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int idx = tid + i * NTHR, row = idx / VCH, ch = idx - row * VCH;
@@ -401,29 +403,43 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
     v_one[i] = SR && row == d;
     v_lds[i] = idx < DT * 16 * VCH ? K_BYTES + row * VROW + ch * 16 : -1;
     v_k8[i] = ch * EPC;
-    v_src[i] = vbase + (int64_t)(row < d ? row : 0) * p.ldt;
+    v_boff[i] = (unsigned)(row < d ? row : 0) * (unsigned)p.ldt * 2u;
+  }
+  // The padding chunks of a tile (channels >= d of K with the LAZY shift channel = 1.0, rows >= d of V^T with the ones row) are the
+  // same for every tile: written once into every ring slot here, so that in the loop only lanes with real data load and store.
+  // (Merging a constant into the loaded register instead made hipcc wait for the load right where it was issued -- the merged
+  // value lived in non-consecutive registers -- which exposed one full L2 round trip per tile: 750 -> 657 us at B16 T4096 d40.)
+  constexpr int NS = 3 * STG;
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl) {
+    char* bs = smem + sl * TILE_B;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+      if (k_lds[i] >= 0 && !k_ok[i]) *(uint4*)(bs + k_lds[i]) = k_one[i] ? make_uint4(0x00003C00u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+      if (v_lds[i] >= 0 && !v_ok[i])
+        *(uint4*)(bs + v_lds[i]) = v_one[i] ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u) : make_uint4(0, 0, 0, 0);
   }
   uint4 rk[KPT], rv[VPT];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int key = min(k0 + k_key[i], Tk - 1);            // rows past Tk: any valid row, their scores are masked to -inf
-      rk[i] = k_one[i] ? make_uint4(0x00003C00u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
-      if (k_ok[i]) rk[i] = *(const uint4*)(kbase + (int64_t)key * p.k_stride + k_el[i]);
+      if (k_ok[i]) rk[i] = *(const uint4*)(kbase + ((unsigned)key * krow_b + k_boff[i]));
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int key = min(k0 + v_k8[i], p.ldt - EPC);        // columns past Tk meet p = 0
-      rv[i] = v_one[i] ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u) : make_uint4(0, 0, 0, 0);
-      if (v_ok[i]) rv[i] = *(const uint4*)(v_src[i] + key);
+      if (v_ok[i]) rv[i] = *(const uint4*)(vbase + (v_boff[i] + (unsigned)key * 2u));
     }
   };
   auto lstore = [&](int slot) {
     char* bs = smem + slot * TILE_B;
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) if (k_lds[i] >= 0) *(uint4*)(bs + k_lds[i]) = rk[i];
+    for (int i = 0; i < KPT; ++i) if (k_ok[i]) *(uint4*)(bs + k_lds[i]) = rk[i];
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) if (v_lds[i] >= 0) *(uint4*)(bs + v_lds[i]) = rv[i];
+    for (int i = 0; i < VPT; ++i) if (v_ok[i]) *(uint4*)(bs + v_lds[i]) = rv[i];
   };
 
   // ---- pipeline pieces
@@ -548,7 +564,6 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   };
 
   // ---- prologue: tiles 0..2*STG into the ring, tile 2*STG+1 in registers, S(0) and its row max
-  constexpr int NS = 3 * STG;
 #pragma unroll
   for (int u = 0; u <= 2 * STG; ++u)
     if (u < NT) { gload(u * KV); lstore(u); }
@@ -727,7 +742,16 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
         //  3 or 4 waves per SIMD spill 190-700 B; 32-key tiles (KTB = 2) fit in 218 registers without a spill but double the
         //  barriers: 847 vs 744 us.  Timing with the per-tile barrier + loads compiled out: 551 us of the 752, with v_exp_f32 replaced by
         //  a multiply: no change -> the loop is bound by the tile hand-off and by LDS-read / MFMA dependency waits at two waves per
-        //  SIMD, not by the transcendental rate; profiles/r02_attention_pmc.txt)
+        //  SIMD, not by the transcendental rate; profiles/r02_attention_pmc.txt.  After the staging fix above (657 us): rotating the
+        //  tile order per workgroup 665, s_setprio 1 for waves 4-7 655, all V^T fragments of a tile read under the QK^T / exp phase
+        //  699 -- the hand-off is no longer what binds; the vector issue sum of a wave-tile (28 MFMA x 8 + 32 v_exp x 8 + ~55 plain
+        //  x 4 = 700 cycles) is used to 50 % by the two lock-stepped waves of a SIMD.  A ping-pong form of the same loop -- waves 0-3
+        //  in a matrix-only phase (QK^T of tile t+1, PV of tile t, all 14 LDS fragment reads issued up front) while waves 4-7 are in
+        //  the vector-only phase (row max, lazy shift, exp2, pack, staging) and vice versa, one s_barrier per phase -- is parity clean
+        //  and slower: 725 us.  With the vector phase compiled out it takes 481 us, without the staging 593 us: the vector work of one
+        //  wave does NOT hide under the partner's MFMAs, because every MFMA holds the SIMD's vector issue port for 8 of its 16 cycles;
+        //  both forms share the issue floor of ~1430 cycles per pair of wave-tiles (= 330 us), and what is left to remove is issue
+        //  cost itself: 32x32x16 MFMAs (half the holds per FLOP) and fewer max / pack instructions -- a different fragment layout.)
         static const int stg = getenv("SR_ATTN_STG") ? atoi(getenv("SR_ATTN_STG")) : 1;           // A-B aid: tiles per barrier
         if (nthr == 512 && lazy && ktb == 4 && stg == 2) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 4, 2, 2>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 4, 2, 2>(*a, st);
         if (nthr == 512 && lazy && ktb == 4 && stg == 3) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 4, 2, 3>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 4, 2, 3>(*a, st);

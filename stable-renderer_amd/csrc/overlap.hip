@@ -122,34 +122,46 @@ __global__ void overlap_fill(const int4* __restrict__ ids, const int* __restrict
 
 // ---- per step ---------------------------------------------------------------------------------------------------------------
 // blended[n,c,cell] = (1-r)*x + r*mean over every pixel that carries the cell's winning vertexID (corresponder.py:339-369).
-// Eight lanes per latent cell walk the vertex's segment; the sum is taken in 2^-28 fixed point (int64: exact, so neither the
+// Sixteen lanes per latent cell walk the vertex's segment; the sum is taken in 2^-28 fixed point (int64: exact, so neither the
 // segment order nor the lane split can change a bit of the result; |x| is clamped to 4096, 2^21 pixels of one vertex still fit).
 constexpr float FIX_SCALE = 268435456.0f;                   // 2^28
 __device__ __forceinline__ long long to_fix(float v) {
   v = fminf(fmaxf(v, -4096.0f), 4096.0f);
   return (long long)(v * FIX_SCALE);                        // power-of-two scaling is exact; the conversion truncates below 2^-28
 }
+constexpr int BLEND_LANES = 16;                            // lanes that share one latent cell's segment walk
 template <int C>
 __global__ __launch_bounds__(256) void overlap_blend(const float* __restrict__ x, const int* __restrict__ cell_vid, const int* __restrict__ off,
                                                      const int* __restrict__ entries, int ncell, int lhw, int cap, float ratio,
                                                      float* __restrict__ blended) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const int cell = t >> 3, l = t & 7;
-  if (cell >= ncell) return;                                // (whole 8-lane groups leave together)
+  const int cell = t / BLEND_LANES, l = t % BLEND_LANES;
+  if (cell >= ncell) return;                                // (whole lane groups leave together)
   const int vid = cell_vid[cell];
   const int f = cell / lhw, p = cell - f * lhw;
   long long acc[C];
   for (int c = 0; c < C; ++c) acc[c] = 0;
   int b = 0, e = 0;
   if (vid >= 0 && vid < cap) { b = off[vid]; e = off[vid + 1]; }
-  for (int i = b + l; i < e; i += 8) {
+  // two independent entry -> latent chains in flight per lane (the walk is a chain of dependent L2 round trips)
+  int i = b + l;
+  for (; i + BLEND_LANES < e; i += 2 * BLEND_LANES) {
+    const int c0 = entries[i], c1 = entries[i + BLEND_LANES];
+    const int f0 = c0 / lhw, f1 = c1 / lhw;
+    const float* x0 = x + (int64_t)f0 * C * lhw + (c0 - f0 * lhw);
+    const float* x1 = x + (int64_t)f1 * C * lhw + (c1 - f1 * lhw);
+    float v0[C], v1[C];
+    for (int c = 0; c < C; ++c) { v0[c] = x0[(int64_t)c * lhw]; v1[c] = x1[(int64_t)c * lhw]; }
+    for (int c = 0; c < C; ++c) acc[c] += to_fix(v0[c]) + to_fix(v1[c]);
+  }
+  if (i < e) {
     const int ce = entries[i];
     const int fe = ce / lhw, pe = ce - fe * lhw;
     const float* xe = x + (int64_t)fe * C * lhw + pe;
     for (int c = 0; c < C; ++c) acc[c] += to_fix(xe[(int64_t)c * lhw]);
   }
   for (int c = 0; c < C; ++c)
-    for (int o = 1; o < 8; o <<= 1) acc[c] += __shfl_xor(acc[c], o, 8);
+    for (int o = 1; o < BLEND_LANES; o <<= 1) acc[c] += __shfl_xor(acc[c], o, BLEND_LANES);
   if (l < C) {
     long long mine = acc[0];
     for (int c = 1; c < C; ++c) mine = (l == c) ? acc[c] : mine;
@@ -175,24 +187,54 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
-// one block per (n, c) plane: AdaIN(content = x, style = blended) -> x in place (corresponder.py:371-376)
-__global__ __launch_bounds__(256) void overlap_apply(float* x, const float* __restrict__ blended, int lhw, float eps) {
-  __shared__ float red[4];
+// one block per (n, c) plane: AdaIN(content = x, style = blended) -> x in place (corresponder.py:371-376).  1024 threads; a plane
+// of up to APPLY_REG * 1024 values (64x64 .. 128x128 latents) is read ONCE into registers, both moments come from there.
+constexpr int APPLY_T = 1024, APPLY_REG = 16;
+__global__ __launch_bounds__(APPLY_T) void overlap_apply(float* x, const float* __restrict__ blended, int lhw, float eps) {
+  __shared__ float red[APPLY_T / 64];
   float* xp = x + (int64_t)blockIdx.x * lhw;
   const float* bp = blended + (int64_t)blockIdx.x * lhw;
+  const bool in_regs = lhw <= APPLY_REG * APPLY_T;
+  float xv[APPLY_REG], bv[APPLY_REG];
   float sc = 0.f, ss = 0.f;
-  for (int p = threadIdx.x; p < lhw; p += 256) { sc += xp[p]; ss += bp[p]; }
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < APPLY_REG; ++k) {
+      const int p = threadIdx.x + k * APPLY_T;
+      xv[k] = p < lhw ? xp[p] : 0.f; bv[k] = p < lhw ? bp[p] : 0.f;
+      sc += xv[k]; ss += bv[k];
+    }
+  } else {
+    for (int p = threadIdx.x; p < lhw; p += APPLY_T) { sc += xp[p]; ss += bp[p]; }
+  }
   const float mc = block_sum(sc, red) / (float)lhw;
   const float ms = block_sum(ss, red) / (float)lhw;
   float qc = 0.f, qs = 0.f;
-  for (int p = threadIdx.x; p < lhw; p += 256) {
-    const float a = xp[p] - mc, b = bp[p] - ms;
-    qc += a * a; qs += b * b;
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < APPLY_REG; ++k) {
+      const int p = threadIdx.x + k * APPLY_T;
+      const float a = xv[k] - mc, b = bv[k] - ms;
+      if (p < lhw) { qc += a * a; qs += b * b; }
+    }
+  } else {
+    for (int p = threadIdx.x; p < lhw; p += APPLY_T) {
+      const float a = xp[p] - mc, b = bp[p] - ms;
+      qc += a * a; qs += b * b;
+    }
   }
   const float stdc = sqrtf(block_sum(qc, red) / (float)(lhw - 1) + eps);
   const float stds = sqrtf(block_sum(qs, red) / (float)(lhw - 1) + eps);
-  __syncthreads();
-  for (int p = threadIdx.x; p < lhw; p += 256) xp[p] = (xp[p] - mc) / stdc * stds + ms;
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < APPLY_REG; ++k) {
+      const int p = threadIdx.x + k * APPLY_T;
+      if (p < lhw) xp[p] = (xv[k] - mc) / stdc * stds + ms;
+    }
+  } else {
+    __syncthreads();
+    for (int p = threadIdx.x; p < lhw; p += APPLY_T) xp[p] = (xp[p] - mc) / stdc * stds + ms;
+  }
 }
 
 // generic AdaIN: one block per (n,c)
@@ -530,14 +572,14 @@ extern "C" int sr_overlap_step(float* x, const int32_t* cell_vid, const int32_t*
   if (C < 1 || C > 8) SR_FAIL(SR_ERR_INVALID, "sr_overlap_step: 1 <= C <= 8");
   hipStream_t st = sr_stream(stream);
   const int ncell = N * lh * lw, lhw = lh * lw;
-  const dim3 grid((unsigned)(((int64_t)ncell * 8 + 255) / 256));
+  const dim3 grid((unsigned)(((int64_t)ncell * BLEND_LANES + 255) / 256));
 #define SR_BLEND(CC) hipLaunchKernelGGL(overlap_blend<CC>, grid, dim3(256), 0, st, x, cell_vid, vid_off, entries, ncell, lhw, vid_capacity, ratio, blended)
   switch (C) {
     case 1: SR_BLEND(1); break; case 2: SR_BLEND(2); break; case 3: SR_BLEND(3); break; case 4: SR_BLEND(4); break;
     case 5: SR_BLEND(5); break; case 6: SR_BLEND(6); break; case 7: SR_BLEND(7); break; default: SR_BLEND(8); break;
   }
 #undef SR_BLEND
-  hipLaunchKernelGGL(overlap_apply, dim3(N * C), dim3(256), 0, st, x, blended, lhw, 1e-5f);
+  hipLaunchKernelGGL(overlap_apply, dim3(N * C), dim3(APPLY_T), 0, st, x, blended, lhw, 1e-5f);
   SR_CHECK_LAUNCH("sr_overlap_step");
   return SR_OK;
 }
