@@ -12,7 +12,12 @@
  * DEFINES the rasterisation rule the HIP rasterizer must reproduce bit for bit:
  *   - vertices to 28.4 fixed point (round half away from zero via floorf(x*16+0.5)), integer edge functions, top-left
  *     fill rule, pixel centres at (x+0.5, y+0.5), row 0 = top of the image (the reference flips GL rows on read-back);
- *   - triangles with any clip w <= 0 are dropped (no near-plane clipping; scenes keep geometry in front of the camera);
+ *   - near / far clipping per fragment: a fragment whose window depth leaves [0, 1] is discarded (what GL's clip against the
+ *     near and far planes leaves of a triangle); a triangle with one or two vertices at clip w <= 0 (behind the eye, where the
+ *     perspective divide is meaningless) is rasterised in homogeneous coordinates -- edge functions from the inverse of the
+ *     clip-space (x, y, w) matrix evaluated at the pixel's NDC centre (Olano & Greer), inclusive edges, the same
+ *     perspective-correct interpolation -- over the whole viewport; all three at w <= 0: dropped.  No GL output exists for
+ *     such triangles in the reference (its scenes keep geometry in front of the camera): this path is defined here;
  *   - barycentrics b_i = (float)E_i / (float)area, perspective-correct attributes sum(a_i b_i/w_i) / sum(b_i/w_i)
  *     in the association order written below, window depth z = sum(z_i b_i), GL_LESS against a 1.0-cleared buffer;
  *   - flat vertexID = last vertex of the triangle (GL provoking vertex), textures sampled NEAREST with REPEAT;
@@ -146,45 +151,80 @@ void ref_raster_draw(const ref_draw* d, ref_gbuffer* g) {
   for (int t = 0; t < d->nt; ++t) {
     vtx v[3];
     for (int k = 0; k < 3; ++k) run_vertex(d, d->tris[3 * t + k], &v[k]);
-    if (!(v[0].cw > 0.0f && v[1].cw > 0.0f && v[2].cw > 0.0f)) continue;
-    int fx[3], fy[3]; float z[3], iw[3];
-    for (int k = 0; k < 3; ++k) {
-      iw[k] = 1.0f / v[k].cw;
-      float nx = v[k].cx * iw[k], ny = v[k].cy * iw[k], nz = v[k].cz * iw[k];
-      float sx = (nx * 0.5f + 0.5f) * (float)W;
-      float sy = (1.0f - (ny * 0.5f + 0.5f)) * (float)H;
-      z[k] = nz * 0.5f + 0.5f;
-      fx[k] = to_fixed(sx); fy[k] = to_fixed(sy);
+    const int nfront = (v[0].cw > 0.0f) + (v[1].cw > 0.0f) + (v[2].cw > 0.0f);
+    if (nfront == 0) continue;
+    const int homog = nfront < 3;
+    int fx[3] = {0, 0, 0}, fy[3] = {0, 0, 0}; float z[3] = {0, 0, 0}, iw[3] = {0, 0, 0};
+    int sgn = 1, tl[3] = {0, 0, 0}; float farea = 1.0f;
+    int x0 = 0, x1 = W - 1, y0 = 0, y1 = H - 1;
+    float E[9];
+    if (!homog) {
+      for (int k = 0; k < 3; ++k) {
+        iw[k] = 1.0f / v[k].cw;
+        float nx = v[k].cx * iw[k], ny = v[k].cy * iw[k], nz = v[k].cz * iw[k];
+        float sx = (nx * 0.5f + 0.5f) * (float)W;
+        float sy = (1.0f - (ny * 0.5f + 0.5f)) * (float)H;
+        z[k] = nz * 0.5f + 0.5f;
+        fx[k] = to_fixed(sx); fy[k] = to_fixed(sy);
+      }
+      int64_t area = edge(fx[0], fy[0], fx[1], fy[1], fx[2], fy[2]);
+      if (area == 0) continue;
+      /* GL front face = counter-clockwise as seen on screen; with y pointing DOWN in these window coordinates a visually
+         CCW triangle has a NEGATIVE edge-function area */
+      if (area > 0 && d->cull_back) continue;
+      sgn = area > 0 ? 1 : -1;
+      int minx = fx[0], maxx = fx[0], miny = fy[0], maxy = fy[0];
+      for (int k = 1; k < 3; ++k) { if (fx[k] < minx) minx = fx[k]; if (fx[k] > maxx) maxx = fx[k]; if (fy[k] < miny) miny = fy[k]; if (fy[k] > maxy) maxy = fy[k]; }
+      x0 = (minx - 8 + 15) >> 4; x1 = (maxx - 8) >> 4; y0 = (miny - 8 + 15) >> 4; y1 = (maxy - 8) >> 4;
+      if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > W - 1) x1 = W - 1; if (y1 > H - 1) y1 = H - 1;
+      /* edge i is opposite vertex i: e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 */
+      tl[0] = top_left(sgn * (fx[2] - fx[1]), sgn * (fy[2] - fy[1]));
+      tl[1] = top_left(sgn * (fx[0] - fx[2]), sgn * (fy[0] - fy[2]));
+      tl[2] = top_left(sgn * (fx[1] - fx[0]), sgn * (fy[1] - fy[0]));
+      farea = (float)(sgn * area);
+    } else {
+      /* rows of the inverse of M = [(cx, cy, cw)_i]: e_i(X, Y) = (E[3i] X + E[3i+1] Y) + E[3i+2] = lambda_i / w at the pixel */
+      float cof[9];
+      for (int i = 0; i < 3; ++i) {
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        cof[3 * i] = v[j].cy * v[k].cw - v[k].cy * v[j].cw;
+        cof[3 * i + 1] = v[k].cx * v[j].cw - v[j].cx * v[k].cw;
+        cof[3 * i + 2] = v[j].cx * v[k].cy - v[k].cx * v[j].cy;
+      }
+      const float det = (v[0].cx * cof[0] + v[0].cy * cof[1]) + v[0].cw * cof[2];
+      if (det == 0.0f) continue;
+      if (det < 0.0f && d->cull_back) continue;                  /* front faces have det > 0 (= negative window area above) */
+      for (int i = 0; i < 9; ++i) E[i] = cof[i] / det;
     }
-    int64_t area = edge(fx[0], fy[0], fx[1], fy[1], fx[2], fy[2]);
-    if (area == 0) continue;
-    /* GL front face = counter-clockwise as seen on screen; with y pointing DOWN in these window coordinates a visually
-       CCW triangle has a NEGATIVE edge-function area */
-    if (area > 0 && d->cull_back) continue;
-    int sgn = area > 0 ? 1 : -1;
-    int minx = fx[0], maxx = fx[0], miny = fy[0], maxy = fy[0];
-    for (int k = 1; k < 3; ++k) { if (fx[k] < minx) minx = fx[k]; if (fx[k] > maxx) maxx = fx[k]; if (fy[k] < miny) miny = fy[k]; if (fy[k] > maxy) maxy = fy[k]; }
-    int x0 = (minx - 8 + 15) >> 4, x1 = (maxx - 8) >> 4, y0 = (miny - 8 + 15) >> 4, y1 = (maxy - 8) >> 4;
-    if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0; if (x1 > W - 1) x1 = W - 1; if (y1 > H - 1) y1 = H - 1;
-    /* edge i is opposite vertex i: e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 */
-    int tl[3];
-    tl[0] = top_left(sgn * (fx[2] - fx[1]), sgn * (fy[2] - fy[1]));
-    tl[1] = top_left(sgn * (fx[0] - fx[2]), sgn * (fy[0] - fy[2]));
-    tl[2] = top_left(sgn * (fx[1] - fx[0]), sgn * (fy[1] - fy[0]));
-    const float farea = (float)(sgn * area);
     for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) {
-      int px = x * 16 + 8, py = y * 16 + 8;
-      int64_t w0 = sgn * edge(fx[1], fy[1], fx[2], fy[2], px, py);
-      int64_t w1 = sgn * edge(fx[2], fy[2], fx[0], fy[0], px, py);
-      int64_t w2 = sgn * edge(fx[0], fy[0], fx[1], fy[1], px, py);
-      if (w0 < 0 || w1 < 0 || w2 < 0) continue;
-      if ((w0 == 0 && !tl[0]) || (w1 == 0 && !tl[1]) || (w2 == 0 && !tl[2])) continue;
-      const float b0 = (float)w0 / farea, b1 = (float)w1 / farea, b2 = (float)w2 / farea;
-      const float zf = (z[0] * b0 + z[1] * b1) + z[2] * b2;           /* gl_FragCoord.z */
+      float f0, f1, f2, fs, zf;
+      if (!homog) {
+        int px = x * 16 + 8, py = y * 16 + 8;
+        int64_t w0 = sgn * edge(fx[1], fy[1], fx[2], fy[2], px, py);
+        int64_t w1 = sgn * edge(fx[2], fy[2], fx[0], fy[0], px, py);
+        int64_t w2 = sgn * edge(fx[0], fy[0], fx[1], fy[1], px, py);
+        if (w0 < 0 || w1 < 0 || w2 < 0) continue;
+        if ((w0 == 0 && !tl[0]) || (w1 == 0 && !tl[1]) || (w2 == 0 && !tl[2])) continue;
+        const float b0 = (float)w0 / farea, b1 = (float)w1 / farea, b2 = (float)w2 / farea;
+        zf = (z[0] * b0 + z[1] * b1) + z[2] * b2;                     /* gl_FragCoord.z */
+        f0 = b0 * iw[0]; f1 = b1 * iw[1]; f2 = b2 * iw[2];
+      } else {
+        const float X = (((float)x + 0.5f) / (float)W) * 2.0f - 1.0f;
+        const float Y = 1.0f - (((float)y + 0.5f) / (float)H) * 2.0f;
+        f0 = (E[0] * X + E[1] * Y) + E[2];
+        f1 = (E[3] * X + E[4] * Y) + E[5];
+        f2 = (E[6] * X + E[7] * Y) + E[8];
+        if (!(f0 >= 0.0f && f1 >= 0.0f && f2 >= 0.0f)) continue;
+        const float es = (f0 + f1) + f2;
+        if (!(es > 0.0f)) continue;
+        const float zc = (v[0].cz * f0 + v[1].cz * f1) + v[2].cz * f2;
+        const float wc = (v[0].cw * f0 + v[1].cw * f1) + v[2].cw * f2;
+        zf = (zc / wc) * 0.5f + 0.5f;
+      }
+      if (!(zf >= 0.0f && zf <= 1.0f)) continue;                     /* near / far clip */
       const size_t pi = (size_t)y * W + x;
       if (d->depth_test) { if (!(zf < g->zbuf[pi])) continue; }
-      const float f0 = b0 * iw[0], f1 = b1 * iw[1], f2 = b2 * iw[2];
-      const float fs = (f0 + f1) + f2;
+      fs = (f0 + f1) + f2;
 #define INTERP(a0, a1, a2) ((((a0) * f0 + (a1) * f1) + (a2) * f2) / fs)
       float vp[3], vn[3], uv[2], vc[3];
       for (int k = 0; k < 3; ++k) { vp[k] = INTERP(v[0].vp[k], v[1].vp[k], v[2].vp[k]); vn[k] = INTERP(v[0].vn[k], v[1].vn[k], v[2].vn[k]); vc[k] = INTERP(v[0].col[k], v[1].col[k], v[2].col[k]); }

@@ -23,6 +23,8 @@ constexpr float PI_F = 3.14159265359f;
 constexpr float CANNY_THRESHOLD = 0.17364817766693041f;   // cos(PI*4/9)
 constexpr int NON_AI_OBJ_MAP_INDEX = 2048;
 
+// valid = 2: a triangle with one or two vertices at clip w <= 0, rasterised in homogeneous coordinates (oracle/raster_ref.c header):
+// fx, fy, z then hold the nine inverse-matrix coefficients E (as float bits), iw the clip z and pad[0..2] the clip w of the vertices
 struct __attribute__((aligned(16))) TriRec {
   int x0, x1, y0, y1;                     // pixel bbox (inclusive), first so the binning pass reads one int4
   int fx[3], fy[3];                       // 28.4 fixed-point window coordinates
@@ -112,7 +114,8 @@ __global__ void raster_setup(const sr_draw d, TriRec* __restrict__ recs, int W, 
     for (int j = 0; j < 3; ++j) r.col[3 * k + j] = d.color ? d.color[3 * idx + j] : 0.0f;
     if (k == 2) r.vid = d.vertex_id ? d.vertex_id[idx] : idx;         // flat: provoking (last) vertex
   }
-  if (cw[0] > 0.0f && cw[1] > 0.0f && cw[2] > 0.0f) {
+  const int nfront = (cw[0] > 0.0f) + (cw[1] > 0.0f) + (cw[2] > 0.0f);
+  if (nfront == 3) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       r.iw[k] = 1.0f / cw[k];
@@ -136,6 +139,29 @@ __global__ void raster_setup(const sr_draw d, TriRec* __restrict__ recs, int W, 
              (top_left(sgn * (r.fx[1] - r.fx[0]), sgn * (r.fy[1] - r.fy[0])) << 2);
       r.farea = (float)((long long)sgn * area);
       r.valid = (r.x0 <= r.x1 && r.y0 <= r.y1) ? 1 : 0;
+    }
+  } else if (nfront > 0) {
+    float cof[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int j = (i + 1) % 3, k = (i + 2) % 3;
+      cof[3 * i] = cy[j] * cw[k] - cy[k] * cw[j];
+      cof[3 * i + 1] = cx[k] * cw[j] - cx[j] * cw[k];
+      cof[3 * i + 2] = cx[j] * cy[k] - cx[k] * cy[j];
+    }
+    const float det = (cx[0] * cof[0] + cy[0] * cof[1]) + cw[0] * cof[2];
+    if (det != 0.0f && !(det < 0.0f && d.cull_back)) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        r.fx[i] = __float_as_int(cof[i] / det);
+        r.fy[i] = __float_as_int(cof[3 + i] / det);
+        r.z[i] = cof[6 + i] / det;
+        r.iw[i] = cz[i];
+        r.pad[i] = __float_as_int(cw[i]);
+      }
+      r.x0 = 0; r.x1 = W - 1; r.y0 = 0; r.y1 = H - 1;
+      r.sgn = 1; r.tl = 0; r.farea = 1.0f;
+      r.valid = 2;
     }
   }
   recs[t] = r;
@@ -224,15 +250,31 @@ __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gb
         for (int j = 0; j < ns; ++j) {
           const TriRec& T = srec[j];
           if (x < T.x0 || x > T.x1 || y < T.y0 || y > T.y1) continue;
-          const long long w0 = (long long)T.sgn * edge_fn(T.fx[1], T.fy[1], T.fx[2], T.fy[2], px, py);
-          const long long w1 = (long long)T.sgn * edge_fn(T.fx[2], T.fy[2], T.fx[0], T.fy[0], px, py);
-          const long long w2 = (long long)T.sgn * edge_fn(T.fx[0], T.fy[0], T.fx[1], T.fy[1], px, py);
-          if (w0 < 0 || w1 < 0 || w2 < 0) continue;
-          if ((w0 == 0 && !(T.tl & 1)) || (w1 == 0 && !(T.tl & 2)) || (w2 == 0 && !(T.tl & 4))) continue;
-          const float b0 = (float)w0 / T.farea, b1 = (float)w1 / T.farea, b2 = (float)w2 / T.farea;
-          const float zf = (T.z[0] * b0 + T.z[1] * b1) + T.z[2] * b2;
+          float f0, f1, f2, zf;
+          if (T.valid != 2) {
+            const long long w0 = (long long)T.sgn * edge_fn(T.fx[1], T.fy[1], T.fx[2], T.fy[2], px, py);
+            const long long w1 = (long long)T.sgn * edge_fn(T.fx[2], T.fy[2], T.fx[0], T.fy[0], px, py);
+            const long long w2 = (long long)T.sgn * edge_fn(T.fx[0], T.fy[0], T.fx[1], T.fy[1], px, py);
+            if (w0 < 0 || w1 < 0 || w2 < 0) continue;
+            if ((w0 == 0 && !(T.tl & 1)) || (w1 == 0 && !(T.tl & 2)) || (w2 == 0 && !(T.tl & 4))) continue;
+            const float b0 = (float)w0 / T.farea, b1 = (float)w1 / T.farea, b2 = (float)w2 / T.farea;
+            zf = (T.z[0] * b0 + T.z[1] * b1) + T.z[2] * b2;
+            f0 = b0 * T.iw[0]; f1 = b1 * T.iw[1]; f2 = b2 * T.iw[2];
+          } else {
+            const float X = (((float)x + 0.5f) / (float)W) * 2.0f - 1.0f;
+            const float Y = 1.0f - (((float)y + 0.5f) / (float)H) * 2.0f;
+            f0 = (__int_as_float(T.fx[0]) * X + __int_as_float(T.fx[1]) * Y) + __int_as_float(T.fx[2]);
+            f1 = (__int_as_float(T.fy[0]) * X + __int_as_float(T.fy[1]) * Y) + __int_as_float(T.fy[2]);
+            f2 = (T.z[0] * X + T.z[1] * Y) + T.z[2];
+            if (!(f0 >= 0.0f && f1 >= 0.0f && f2 >= 0.0f)) continue;
+            const float es = (f0 + f1) + f2;
+            if (!(es > 0.0f)) continue;
+            const float zc = (T.iw[0] * f0 + T.iw[1] * f1) + T.iw[2] * f2;
+            const float wc = (__int_as_float(T.pad[0]) * f0 + __int_as_float(T.pad[1]) * f1) + __int_as_float(T.pad[2]) * f2;
+            zf = (zc / wc) * 0.5f + 0.5f;
+          }
+          if (!(zf >= 0.0f && zf <= 1.0f)) continue;               // near / far clip
           if (d.depth_test) { if (!(zf < zcur)) continue; }
-          const float f0 = b0 * T.iw[0], f1 = b1 * T.iw[1], f2 = b2 * T.iw[2];
           const float fs = (f0 + f1) + f2;
 #define INTERP(a0, a1, a2) ((((a0) * f0 + (a1) * f1) + (a2) * f2) / fs)
           float vp[3], vn[3], uv[2], vc[3];

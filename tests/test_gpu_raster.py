@@ -238,3 +238,33 @@ def test_identical_gbuffer_merge_and_display_pass():
     tinted = gb.display(is_baking=True).cpu().numpy()
     plain = gb.display(is_baking=False).cpu().numpy()
     assert (np.abs(tinted - plain).max(-1) > 0.01).sum() > 1000
+
+
+def test_near_plane_crossing_triangles_bit_exact():
+    """a ground quad that runs through the near plane and behind the eye (homogeneous rasterisation path) + an ordinary sphere
+    standing on it: all seven planes equal to the C oracle's"""
+    from stable_renderer_amd import scene as S
+    import raster_ref as R
+    from test_raster_clip import ground_scene
+    W, H = 320, 200
+    cam, quad, model = ground_scene(W, H)
+    g = torch.Generator().manual_seed(3)
+    diffuse = torch.rand(32, 32, 4, generator=g)
+    tasks = [S.DrawTask(quad, model, sprite_id=3, material_id=4, render_mode=0, diffuse_tex=diffuse, order=999.5),
+             S.DrawTask(S.Mesh.Sphere(12), S.matmul(S.translate((0.2, 0.5, -2.5)), S.scale(0.5)), sprite_id=1, material_id=1,
+                        render_mode=0, order=999.7)]
+    gb = S.GBuffer(W, H)
+    gb.render(tasks, cam)
+    torch.cuda.synchronize()
+    ref = R.GBufferRef(W, H)
+    ref.clear()
+    view, proj = cam.view(), cam.projection(W / H)
+    for t in tasks:
+        ref.draw(t, S.draw_params(t, view, proj), diffuse_tex=None if t.diffuse_tex is None else t.diffuse_tex.numpy())
+    assert (ref.id[-1, :, 0] == 3).all() and (ref.id[..., 0] == 1).any()
+    assert np.array_equal(gb.id.cpu().numpy(), ref.id)
+    assert np.array_equal(gb.zbuf.cpu().numpy().view(np.uint32), ref.zbuf.view(np.uint32))
+    assert np.array_equal(gb.color.cpu().numpy().view(np.uint16), ref.color)
+    assert np.array_equal(gb.normal_depth.cpu().numpy().view(np.uint16), ref.normal_depth)
+    assert np.array_equal(gb.pos.cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
+    assert np.array_equal(gb.canny.cpu().numpy(), ref.canny)
