@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--mode", default="replica", choices=["replica", "shard"],
                     help="replica: every GPU bakes its own 8-view group (weak scaling, no collective); shard: ONE 8-view group "
                          "split over the GPUs with the latent all-gather / K,V-source broadcast over RCCL (strong scaling)")
+    ap.add_argument("--workload", default="sd15-512", choices=["sd15-512", "sdxl-1024"],
+                    help="sd15-512: the configuration BASELINE.json's metric is quoted on (default); sdxl-1024: BASELINE config 5, "
+                         "the SDXL base UNet (2.57 B parameters) at 1024x1024 through the same raster / overlap / K-V injection / "
+                         "VAE / corr-map path (one call at a time: a slot holds ~120 GB of plans)")
     ap.add_argument("--controlnets", action="store_true",
                     help="attach the depth + normal ControlNet pair driven by the G-buffers (BASELINE config 4's composition)")
     a = ap.parse_args()
@@ -101,8 +105,17 @@ def main():
         from stable_renderer_amd.parallel import ViewShard
         shard = ViewShard(a.views)
     controls = [("depth", 1.0), ("normal", 1.0)] if a.controlnets else None     # BASELINE config 4's pair (miku-control.json)
+    sdxl = a.workload == "sdxl-1024"
+    res = 1024 if sdxl else 512
+    extra = {}
+    if sdxl:
+        from stable_renderer_amd.unet import SDXL_CFG
+        extra = dict(W=1024, H=1024, unet_cfg=dict(SDXL_CFG))
+        a.inflight, a.no_cpu_baseline = 1, True               # the CPU port of this size takes hours: not a bounded sample
     pipe = build_sd15_pipeline(dtype=dtype, n_views=a.views, steps=a.denoise_steps, cfg=8.0, use_graph=not a.no_graph,
-                               device="cuda:%d" % local, shard=shard, controls=controls)
+                               device="cuda:%d" % local, shard=shard, controls=controls, **extra)
+    if sdxl:
+        pipe.runner.set_vector_conditioning(torch.randn(1, SDXL_CFG["adm_in_channels"], generator=torch.Generator().manual_seed(3)))
     pipe.runner.time_comm = shard is not None
     torch.manual_seed(1234 + rank)
 
@@ -197,12 +210,12 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         peak = 2500.0 if a.dtype == "f16" else 157.3
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "igemm family: igemm_kernel tiles + conv3p_kernel (implicit-GEMM conv/linear, all %d launches of one UNet eval, B=%d)" % (sub.n, a.views * 2),
+        roof = {"bound": "mfma", "kernel": "igemm family: igemm_kernel tiles + conv3p_kernel (implicit-GEMM conv/linear, all %d launches of one UNet eval, B=%d)" % (sub.n, (a.views // world if shard is not None else a.views) * 2),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 # HBM-side bytes of these launches per UNet evaluation from the FETCH_SIZE (x2, gfx950) + WRITE_SIZE PMC passes of
                 # this very replay (tools/profile_round.sh -> profiles/r02_igemm_traffic.json); PMC cannot be collected from
                 # inside the process, so the figure is the recorded one and only quoted for the configuration it was measured on
-                "traffic": MEASURED_IGEMM_TRAFFIC_BYTES if (a.dtype == "f16" and a.views == 8 and shard is None and not a.controlnets) else None,
+                "traffic": MEASURED_IGEMM_TRAFFIC_BYTES if (a.dtype == "f16" and a.views == 8 and shard is None and not a.controlnets and not sdxl) else None,
                 "algorithmic_bytes": sub.igemm_bytes(),
                 "launches": sub.n, "avg_launch_us": round(ms * 1e3 / max(sub.n, 1), 2), "flops_per_eval": flops}
         full = pipe.runner._plan["flops"]
@@ -218,15 +231,16 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
-        out = {"metric": "frames/sec @512^2, SD1.5 20-step img2img, 8-view overlap", "value": round(frames / dt, 4), "unit": "frames/s",
+        out = {"metric": "frames/sec @1024^2, SDXL 20-step img2img, 8-view overlap" if sdxl else "frames/sec @512^2, SD1.5 20-step img2img, 8-view overlap", "value": round(frames / dt, 4), "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 2),
                "higher_is_better": True, "scaling": "strong" if shard is not None else "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "bake_ball.py sphere scene 512x512 (HIP raster, corr-map proxy k=6, texcoord ids) -> SD1.5-shaped UNet "
-                                      "(859.5M params, random init) %d denoise steps ddim/normal cfg 8, %d views per call with "
-                                      "OverlapCorresponder (per-step latent overlap + K/V injection) -> VAE decode %dx512^2 -> corr-map "
+               "config": {"workload": "bake_ball.py sphere scene %dx%d (HIP raster, corr-map proxy k=6, texcoord ids) -> %s UNet "
+                                      "(%s params, random init) %d denoise steps ddim/normal cfg 8, %d views per call with "
+                                      "OverlapCorresponder (per-step latent overlap + K/V injection) -> VAE decode %dx%d^2 -> corr-map "
                                       "update; zero latent + engine noise as the reference bake workflows; one call per step"
-                                      % (a.denoise_steps, a.views, a.views),
-                          "views_per_call": a.views, "denoise_steps": a.denoise_steps, "resolution": 512, "parallelism": ("one group view-sharded x%d" if shard is not None else "view-group replicas x%d") % world,
+                                      % (res, res, "SDXL-base-shaped" if sdxl else "SD1.5-shaped", "2.57B" if sdxl else "859.5M",
+                                         a.denoise_steps, a.views, a.views, res),
+                          "views_per_call": a.views, "denoise_steps": a.denoise_steps, "resolution": res, "parallelism": ("one group view-sharded x%d" if shard is not None else "view-group replicas x%d") % world,
                           "calls_in_flight_per_gpu": inflight, "controlnets": ["depth", "normal"] if a.controlnets else []},
                "exposed_comm_ms_per_denoise_step": None if comm_ms is None else round(comm_ms / max(a.steps * a.denoise_steps, 1), 4),
                "value_1_in_flight": None if one_at_a_time is None else round(one_at_a_time * world, 4),
