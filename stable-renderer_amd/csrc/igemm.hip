@@ -278,6 +278,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     for (int i = 0; i < NIQ; ++i) wrow[i] += (int64_t)kt0 * BKB;
   }
   int s_tap = kt0 / KPT, s_kk = kt0 - s_tap * KPT;
+  // (measured and dropped: starting every tile's K loop at a different K-step, so that concurrent tiles do not ask for the same
+  // weight / activation lines at the same moment: neutral to -10 % on the K-short 1x1 layers -- they are not bound by hot lines)
+  auto advance = [&]() { if (++s_kk == KPT) { s_kk = 0; if (++s_tap < ntaps) set_tap(s_tap); } };
   set_tap(s_tap);
   auto stage = [&](int buf) {                            // issue the async loads of the next K-step
     char* tP = smem + buf * STAGE_BYTES;
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
       for (int i = 0; i < NIQ; ++i) { sr_glds16_asm_nosave(wrow[i], lQ + gq(i)); wrow[i] += BKB; }
       sr_m0_restore(m0);
     }
-    if (++s_kk == KPT) { s_kk = 0; if (++s_tap < ntaps) set_tap(s_tap); }
+    advance();
   };
 
   // ---- fragment read offsets
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
       }
     }
     sr_m0_restore(m0_keep);
-    if (++s_kk == KPT) { s_kk = 0; if (++s_tap < ntaps) set_tap(s_tap); }
+    advance();
   };
   {
     // STAGES-deep LDS ring, loads run D = STAGES-1 K-steps ahead: wait only for the oldest stage (counted vmcnt, never 0
