@@ -16,14 +16,137 @@
 // holding 4 consecutive output channels of one pixel (8/16-byte stores, vector bias/residual loads); with
 // transpose_out the roles swap and a lane holds 4 consecutive pixels of one channel (V^T for attention).
 #include "sr_common.h"
+#ifndef SR_IGEMM_TRACE
+#define SR_IGEMM_TRACE 0        // development only: wave 0 of every workgroup writes wall-clock stamps (100 MHz) of its phases to p.workspace
+#endif
+#if SR_IGEMM_TRACE
+#define SR_TS(k) do { if (threadIdx.x == 0) ts_[k] = wall_clock64(); } while (0)
+#else
+#define SR_TS(k) do { } while (0)
+#endif
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
 
+// fp16-output form of the row-major epilogue (the coalesced path of epilogue_rows below, same arithmetic and the same stores),
+// restructured after a per-workgroup timeline of the K-short layers (tools/trace_igemm.py) showed the epilogue taking 4.4 us of a
+// 12.5 us workgroup lifetime on the 128x160 tile and 8.4 of 23.5 us on 128x320: on CDNA4 vmcnt counts stores too, so every pass
+// that loaded its bias (and every read-back iteration that loaded its residual chunk) AFTER the previous pass's global stores
+// waited for those stores to retire -- ~2 us per pass.  Here no global LOAD of the epilogue follows a store: the tile's bias /
+// colsum rows go through LDS once (read back with ds_read, which vmcnt does not cover), the wave's residual chunks are loaded
+// up front when the register budget VCAP allows, and a pass covers as many 16-row groups as the staging LDS holds at the fp16
+// row size (the old bound assumed fp32 rows).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int LDS_AVAIL, bool GEGLU, int VCAP>
+__device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], char* smem, const int M,
+                                                const int rpb, const int m0, const int n0, const int pm0, const int qn0, const int wv,
+                                                const int lane) {
+  constexpr int NW = WAVES_M * WAVES_N, TM = BM / WAVES_M / 16, TN = BN / WAVES_N / 16;
+  constexpr int WCOLS = BN / WAVES_N, OCOLS = GEGLU ? WCOLS / 2 : WCOLS;
+  constexpr int ROWB = OCOLS * 2 + 16;                       // padded LDS row (bank spread, keeps 16-B alignment)
+  constexpr int CPR = OCOLS * 2 / 16, RPI = 64 / CPR;        // 16-B chunks per row, rows per wave instruction
+  constexpr int VEC_B = 2 * BN * 4;                          // bias + colsum rows of the tile (fp32)
+  constexpr int LDS_ROWS = LDS_AVAIL - VEC_B;
+  constexpr int TMP = (NW * TM * 16 * ROWB <= LDS_ROWS) ? TM : ((TM % 2 == 0 && NW * (TM / 2) * 16 * ROWB <= LDS_ROWS) ? TM / 2 : 1);
+  constexpr int ROWS = TMP * 16, ITER = (ROWS + RPI - 1) / RPI, NPASS = TM / TMP;
+  constexpr bool PRE = TM * TN * 4 + NPASS * ITER * 4 + 48 <= VCAP;     // accumulators + residual chunks + working set
+  static_assert(OCOLS % 8 == 0 && NW * 16 * ROWB <= LDS_ROWS, "epilogue staging");
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const float scale = p.scale;
+  const int N = p.N;
+  const int ldr = p.rowvec_ld ? p.rowvec_ld : N;
+  const int ldo = GEGLU ? (N >> 1) : N;
+  float* lvec = (float*)smem;                                // [BN] bias, [BN] colsum
+  char* wl = smem + VEC_B + wv * (ROWS * ROWB);
+  const int lr = lane / CPR, lc = lane - lr * CPR;
+  const int ncol = (GEGLU ? ((n0 + qn0) >> 1) : (n0 + qn0)) + lc * 8;
+  const bool lane_on = lr < RPI && ncol < ldo;
+  const int tid = wv * 64 + lane;
+
+  // every global load first: the tile's bias / colsum chunk of this thread, the wave's residual chunks
+  float4 vb = make_float4(0.f, 0.f, 0.f, 0.f), vc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool vec_lane = tid < BN / 4 && n0 + tid * 4 < N;
+  if (vec_lane) {
+    if (p.bias) vb = *(const float4*)(p.bias + n0 + tid * 4);
+    if (p.row_stats) vc = *(const float4*)(p.colsum + n0 + tid * 4);
+  }
+  uint4 resid[PRE ? NPASS * ITER : 1];
+  if constexpr (PRE) {
+    if (p.residual) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int row = it * RPI + lr, m = m0 + pm0 + ps * ROWS + row;
+          resid[ps * ITER + it] = make_uint4(0, 0, 0, 0);
+          if (lane_on && row < ROWS && m < M) resid[ps * ITER + it] = *(const uint4*)((const _Float16*)p.residual + (int64_t)m * ldo + ncol);
+        }
+    }
+  }
+  __syncthreads();                                           // every wave is done reading the staging tiles
+  if (tid < BN / 4) { *(float4*)(lvec + tid * 4) = vb; *(float4*)(lvec + BN + tid * 4) = vc; }
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+    for (int t = 0; t < TMP; ++t) {
+      const int tm = ps * TMP + t;
+      const int m = m0 + pm0 + tm * 16 + c16;
+      const int b = (p.rowvec && m < M) ? m / rpb : 0;
+      float2 rs = make_float2(1.f, 0.f);                     // folded LayerNorm: (rstd, -rstd*mean) of input row m
+      if (p.row_stats && m < M) rs = *(const float2*)(p.row_stats + 2 * (int64_t)m);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int nl = qn0 + tn * 16 + 4 * g4, n = n0 + nl;
+        float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
+        if (n < N) {                                         // N % 4 == 0 on this path
+          if (p.row_stats) {
+            const float4 cs = *(const float4*)(lvec + BN + nl);
+            v[0] = fmaf(rs.x, v[0], rs.y * cs.x); v[1] = fmaf(rs.x, v[1], rs.y * cs.y);
+            v[2] = fmaf(rs.x, v[2], rs.y * cs.z); v[3] = fmaf(rs.x, v[3], rs.y * cs.w);
+          }
+          if (p.bias) { const float4 bv = *(const float4*)(lvec + nl); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+          if (p.rowvec) { const float4 rv = *(const float4*)(p.rowvec + (int64_t)b * ldr + n); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+        }
+        if (p.act == 1) { for (int r = 0; r < 4; ++r) v[r] = sr_silu_f(v[r]); }
+        else if (p.act == 3) { for (int r = 0; r < 4; ++r) v[r] = sr_gelu_f(v[r]); }
+        else if (p.act == 4) { for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf((v[r] + 1.0f) * 0.5f, 0.0f), 1.0f); }
+        char* dst = wl + (t * 16 + c16) * ROWB;
+        if constexpr (GEGLU) {
+          const float o0 = v[0] * sr_gelu_f(v[1]), o1 = v[2] * sr_gelu_f(v[3]);
+          h16x2 hv = {(_Float16)o0, (_Float16)o1};
+          *(h16x2*)(dst + (tn * 8 + 2 * g4) * 2) = hv;
+        } else {
+          h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+          *(h16x4*)(dst + (tn * 16 + 4 * g4) * 2) = hv;
+        }
+      }
+    }
+    // read back row-wise (same wave wrote it: no block barrier needed, only the LDS write->read ordering)
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int row = it * RPI + lr, m = m0 + pm0 + ps * ROWS + row;
+      if (!(lane_on && row < ROWS && m < M)) continue;
+      uint4 raw = *(const uint4*)(wl + row * ROWB + lc * 16);
+      const int64_t oi = (int64_t)m * ldo + ncol;
+      if (p.residual) {
+        const h16x8 rr = PRE ? __builtin_bit_cast(h16x8, resid[PRE ? ps * ITER + it : 0]) : *(const h16x8*)((const _Float16*)p.residual + oi);
+        h16x8 hv = __builtin_bit_cast(h16x8, raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (_Float16)((float)hv[e] + (float)rr[e]);
+        raw = __builtin_bit_cast(uint4, hv);
+      }
+      *(uint4*)((_Float16*)p.out + oi) = raw;
+    }
+    __builtin_amdgcn_wave_barrier();                         // (LDS is in order per wave: the next pass may overwrite)
+  }
+}
+
 // Row-major epilogue shared by the tile kernels: bias / time-embedding slice / activation in registers, the wave's sub-tile
 // staged through LDS (`smem`, LDS_AVAIL bytes free for it) for 16-byte coalesced stores and residual loads.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int LDS_AVAIL, bool BLOCK_SYNC = true>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int LDS_AVAIL, bool BLOCK_SYNC = true, int VCAP = 256>
 __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], char* smem, const int M,
                                               const int rpb, const int m0, const int n0, const int pm0, const int qn0, const int wv,
                                               const int lane) {
@@ -36,6 +159,14 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
     const int ldo = (p.act == 2) ? (N >> 1) : N;
     const bool o32 = p.out_f32 || sizeof(T) == 4;
     const int oes = o32 ? 4 : 2;                             // output element size
+    if constexpr (sizeof(T) == 2) {
+      if (!o32 && (ldo * 2) % 16 == 0) {
+        static_assert(BLOCK_SYNC, "the fp16 epilogue synchronises the workgroup itself");
+        if (p.act == 2) epilogue_rows_h<T, BM, BN, WAVES_M, WAVES_N, LDS_AVAIL, true, VCAP>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
+        else            epilogue_rows_h<T, BM, BN, WAVES_M, WAVES_N, LDS_AVAIL, false, VCAP>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
+        return;
+      }
+    }
     if ((ldo * oes) % 16 == 0) {
       // Coalesced path: bias / time-embedding / activation in registers, then the wave's sub-tile goes through LDS
       // (the staging buffers are free now) so that global stores -- and the residual loads -- are whole 16-byte
@@ -205,6 +336,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if SR_IGEMM_TRACE
+  unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  SR_TS(0);
   const int wg = tile0 + sr_xcd_remap(blockIdx.x, nwg);      // this launch covers tiles [tile0, tile0 + nwg)
   const int mt = wg / NT, nt = wg - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -398,6 +533,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     static_assert(PER_STAGE * (D - 1) < 64, "vmcnt immediate");
     const int nk = kt1 - kt0;                            // (split-K: this workgroup's share of the K-steps)
+    SR_TS(1);
 #pragma unroll
     for (int i = 0; i < D; ++i) if (i < nk) stage(i);
     int cur = 0;
@@ -409,6 +545,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
       else if (D == 3 && younger == 1)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
       else                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // stage kt visible to all; everyone finished step kt-1
+      if (kt == 0) SR_TS(2);
       if constexpr (SPREAD == 1) {
         if (kt + D < nk) { int nb = cur + D; if (nb >= STAGES) nb -= STAGES; compute_staging(cur, nb); }
         else compute(cur);
@@ -426,6 +563,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     }
   }
 
+  SR_TS(3);
   // ---- epilogue
   const float scale = p.scale;
   const int N = p.N;
@@ -439,7 +577,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
       for (int tm = 0; tm < TM; ++tm) ws[(tn * TM + tm) * 64] = acc[tn][tm];
     return;
   } else if constexpr (!TRANS) {
-    epilogue_rows<T, BM, BN, WAVES_M, WAVES_N, STAGES * STAGE_BYTES>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
+    epilogue_rows<T, BM, BN, WAVES_M, WAVES_N, STAGES * STAGE_BYTES, true, (MINB >= 4 ? 128 : 256)>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
+#if SR_IGEMM_TRACE
+    SR_TS(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SR_TS(5);
+    if (threadIdx.x == 0 && p.workspace && !SPLIT) { unsigned long long* w_ = (unsigned long long*)p.workspace + (size_t)blockIdx.x * 8; for (int k_ = 0; k_ < 6; ++k_) w_[k_] = ts_[k_]; w_[6] = __smid(); }
+#endif
   } else {
     const bool vec = (rpb % 4 == 0) && (p.ldt % 4 == 0);
 #pragma unroll
@@ -821,7 +965,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // on the 32x32 GEGLU.  (A 3-slot ring of 64-byte K-steps under the 128x160 tile measured 5..10 % behind the 2 x 128-byte form.)
     if (force == 9) {
       if (a.N % 160) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 9 (128x160) needs N %% 160 == 0, N=%d", a.N);
-      return launch<T, 128, 160, 4, 2, 2, TRANS, 128, 0, 2>(a, M, Ho, Wo, st);
+      return launch<T, 128, 160, 4, 2, 2, TRANS, 128, 0, 4>(a, M, Ho, Wo, st);
     }
     if (force == 10) {
       if (a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 10 (128x320) needs N %% 320 == 0, N=%d", a.N);
