@@ -37,7 +37,7 @@ namespace {
 // colsum rows go through LDS once (read back with ds_read, which vmcnt does not cover), the wave's residual chunks are loaded
 // up front when the register budget VCAP allows, and a pass covers as many 16-row groups as the staging LDS holds at the fp16
 // row size (the old bound assumed fp32 rows).
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int LDS_AVAIL, bool GEGLU, int VCAP>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int LDS_AVAIL, bool GEGLU, int VCAP, bool VECPRE>
 __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], char* smem, const int M,
                                                 const int rpb, const int m0, const int n0, const int pm0, const int qn0, const int wv,
                                                 const int lane) {
@@ -46,7 +46,7 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
   constexpr int ROWB = OCOLS * 2 + 16;                       // padded LDS row (bank spread, keeps 16-B alignment)
   constexpr int CPR = OCOLS * 2 / 16, RPI = 64 / CPR;        // 16-B chunks per row, rows per wave instruction
   constexpr int VEC_B = 2 * BN * 4;                          // bias + colsum rows of the tile (fp32)
-  constexpr int LDS_ROWS = LDS_AVAIL - VEC_B;
+  constexpr int LDS_ROWS = VECPRE ? LDS_AVAIL : LDS_AVAIL - VEC_B;   // VECPRE: the kernel put them in front of `smem` by LDS-DMA at its start
   constexpr int TMP = (NW * TM * 16 * ROWB <= LDS_ROWS) ? TM : ((TM % 2 == 0 && NW * (TM / 2) * 16 * ROWB <= LDS_ROWS) ? TM / 2 : 1);
   constexpr int ROWS = TMP * 16, ITER = (ROWS + RPI - 1) / RPI, NPASS = TM / TMP;
   constexpr bool PRE = TM * TN * 4 + NPASS * ITER * 4 + 48 <= VCAP;     // accumulators + residual chunks + working set
@@ -56,8 +56,8 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
   const int N = p.N;
   const int ldr = p.rowvec_ld ? p.rowvec_ld : N;
   const int ldo = GEGLU ? (N >> 1) : N;
-  float* lvec = (float*)smem;                                // [BN] bias, [BN] colsum
-  char* wl = smem + VEC_B + wv * (ROWS * ROWB);
+  float* lvec = (float*)(VECPRE ? smem - VEC_B : smem);      // [BN] bias, [BN] colsum
+  char* wl = smem + (VECPRE ? 0 : VEC_B) + wv * (ROWS * ROWB);
   const int lr = lane / CPR, lc = lane - lr * CPR;
   const int ncol = (GEGLU ? ((n0 + qn0) >> 1) : (n0 + qn0)) + lc * 8;
   const bool lane_on = lr < RPI && ncol < ldo;
@@ -65,10 +65,12 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
 
   // every global load first: the tile's bias / colsum chunk of this thread, the wave's residual chunks
   float4 vb = make_float4(0.f, 0.f, 0.f, 0.f), vc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool vec_lane = tid < BN / 4 && n0 + tid * 4 < N;
-  if (vec_lane) {
-    if (p.bias) vb = *(const float4*)(p.bias + n0 + tid * 4);
-    if (p.row_stats) vc = *(const float4*)(p.colsum + n0 + tid * 4);
+  if constexpr (!VECPRE) {
+    const bool vec_lane = tid < BN / 4 && n0 + tid * 4 < N;
+    if (vec_lane) {
+      if (p.bias) vb = *(const float4*)(p.bias + n0 + tid * 4);
+      if (p.row_stats) vc = *(const float4*)(p.colsum + n0 + tid * 4);
+    }
   }
   uint4 resid[PRE ? NPASS * ITER : 1];
   if constexpr (PRE) {
@@ -84,8 +86,10 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
     }
   }
   __syncthreads();                                           // every wave is done reading the staging tiles
-  if (tid < BN / 4) { *(float4*)(lvec + tid * 4) = vb; *(float4*)(lvec + BN + tid * 4) = vc; }
-  __syncthreads();
+  if constexpr (!VECPRE) {
+    if (tid < BN / 4) { *(float4*)(lvec + tid * 4) = vb; *(float4*)(lvec + BN + tid * 4) = vc; }
+    __syncthreads();
+  }
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
@@ -146,7 +150,7 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
 
 // Row-major epilogue shared by the tile kernels: bias / time-embedding slice / activation in registers, the wave's sub-tile
 // staged through LDS (`smem`, LDS_AVAIL bytes free for it) for 16-byte coalesced stores and residual loads.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int LDS_AVAIL, bool BLOCK_SYNC = true, int VCAP = 256>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int LDS_AVAIL, bool BLOCK_SYNC = true, int VCAP = 256, bool VECPRE = false>
 __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], char* smem, const int M,
                                               const int rpb, const int m0, const int n0, const int pm0, const int qn0, const int wv,
                                               const int lane) {
@@ -162,8 +166,8 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
     if constexpr (sizeof(T) == 2) {
       if (!o32 && (ldo * 2) % 16 == 0) {
         static_assert(BLOCK_SYNC, "the fp16 epilogue synchronises the workgroup itself");
-        if (p.act == 2) epilogue_rows_h<T, BM, BN, WAVES_M, WAVES_N, LDS_AVAIL, true, VCAP>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
-        else            epilogue_rows_h<T, BM, BN, WAVES_M, WAVES_N, LDS_AVAIL, false, VCAP>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
+        if (p.act == 2) epilogue_rows_h<T, BM, BN, WAVES_M, WAVES_N, LDS_AVAIL, true, VCAP, VECPRE>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
+        else            epilogue_rows_h<T, BM, BN, WAVES_M, WAVES_N, LDS_AVAIL, false, VCAP, VECPRE>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
         return;
       }
     }
@@ -320,7 +324,11 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
                                                                         const int NT, const int nwg, const int tile0) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // fp16, unsplit: the tile's bias and colsum rows (2 x BN floats) sit in front of the staging ring, fetched by LDS-DMA below
+  constexpr bool VECPRE = sizeof(T) == 2 && !SPLIT;
+  constexpr int VEC_B = VECPRE ? 2 * BN * 4 : 0;
+  char* const smem = smem_raw + VEC_B;
   constexpr int KE = BKB / (int)sizeof(T);            // elements of K per step
   constexpr int NW = WAVES_M * WAVES_N;               // waves per workgroup (4 or 8)
   constexpr int RPI = 1024 / BKB;                     // tile rows one LDS-DMA wave instruction fills (1 KiB)
@@ -343,6 +351,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
   const int wg = tile0 + sr_xcd_remap(blockIdx.x, nwg);      // this launch covers tiles [tile0, tile0 + nwg)
   const int mt = wg / NT, nt = wg - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
+  if constexpr (VECPRE) {
+    // [bias n0..n0+BN) | colsum n0..n0+BN)] -> LDS, 16 bytes per lane; absent rows / columns past N come from the zero page.
+    // These are the oldest LDS-DMA requests of the wave: the first counted vmcnt wait of the K loop covers them, its barrier
+    // publishes them; the epilogue reads them with ds_read (no global load behind a store there: see epilogue_rows_h)
+    constexpr int CH = BN / 2;                               // 16-byte chunks in all
+    const int c = wv * 64 + lane;
+    if (wv * 64 < CH) {
+      const bool second = c >= BN / 4;
+      const int n = n0 + 4 * (second ? c - BN / 4 : c);
+      const float* base = second ? (p.row_stats ? p.colsum : nullptr) : p.bias;
+      const char* src = (base && n < p.N) ? (const char*)(base + n) : (const char*)p.zero_page;
+      if (c < CH) sr_glds16_asm(src, __builtin_amdgcn_readfirstlane(sr_lds_addr(smem_raw) + wv * 1024));
+    }
+  }
   // LDS-DMA writes lane-linearly (row = lane / chunks-per-row, slot = lane % chunks-per-row), so the bank swizzle is applied to
   // the SOURCE: the lane fetches the logical 16-B chunk whose swizzled slot it fills.  128-B rows: slot = chunk ^ (row & 7).
   // 64-B rows (rows r and r+4 share banks): slot = ((row >> 2) & 3) ^ F[chunk], F = {0,3,1,2}, which makes every 16-lane
@@ -366,8 +388,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     const int gi = (i * NW + wv) < GP ? (i * NW + wv) : GP - 1;
     const int m = m0 + gi * RPI + lrow;
     if (m < M) {
-      const int b = m / rpb, rem = m - b * rpb, oy = rem / Wo;
-      pb[i] = b; py[i] = oy * p.stride - pad; px[i] = (rem - oy * Wo) * p.stride - pad;
+      if (rpb == 1) { pb[i] = m; py[i] = -pad; px[i] = -pad; }      // linear layers (one "pixel" per row): no divisions
+      else {
+        const int b = m / rpb, rem = m - b * rpb, oy = rem / Wo;
+        pb[i] = b; py[i] = oy * p.stride - pad; px[i] = (rem - oy * Wo) * p.stride - pad;
+      }
     } else { pb[i] = -1; py[i] = 0; px[i] = 0; }
   }
   const char* zp = (const char*)p.zero_page + lchunk * 16;
@@ -577,7 +602,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
       for (int tm = 0; tm < TM; ++tm) ws[(tn * TM + tm) * 64] = acc[tn][tm];
     return;
   } else if constexpr (!TRANS) {
-    epilogue_rows<T, BM, BN, WAVES_M, WAVES_N, STAGES * STAGE_BYTES, true, (MINB >= 4 ? 128 : 256)>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
+    epilogue_rows<T, BM, BN, WAVES_M, WAVES_N, STAGES * STAGE_BYTES, true, (MINB >= 4 ? 128 : 256), VECPRE>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
 #if SR_IGEMM_TRACE
     SR_TS(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -631,7 +656,7 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   constexpr int lds_stage = STAGES * (BM + BN) * BKB;
   constexpr int lds_epi_all = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);   // fp32 output sub-tiles of all waves
   constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
-  constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+  constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0);   // + the bias / colsum rows (fp16 kernels)
   auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB, SPREAD, MINB>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
@@ -707,7 +732,7 @@ int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int tile0, int S
   const int MT = (M + BM - 1) / BM, NTv = (a.N + BN - 1) / BN, ntiles = MT * NTv, ntail = ntiles - tile0;
   constexpr int lds_stage = 2 * (BM + BN) * 128;
   constexpr int lds_epi = 4 * (BM / 2) * ((BN / 2) * 4 + 16);
-  constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+  constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0);   // (the unsplit head tiles' bias / colsum rows)
   auto kf = igemm_kernel<T, BM, BN, 2, 2, 2, false, false>;
   auto ks = igemm_kernel<T, BM, BN, 2, 2, 2, false, true>;
   static bool attr_set = false;
