@@ -47,9 +47,18 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
   constexpr int CPR = OCOLS * 2 / 16, RPI = 64 / CPR;        // 16-B chunks per row, rows per wave instruction
   constexpr int VEC_B = 2 * BN * 4;                          // bias + colsum rows of the tile (fp32)
   constexpr int LDS_ROWS = VECPRE ? LDS_AVAIL : LDS_AVAIL - VEC_B;   // VECPRE: the kernel put them in front of `smem` by LDS-DMA at its start
-  constexpr int TMP = (NW * TM * 16 * ROWB <= LDS_ROWS) ? TM : ((TM % 2 == 0 && NW * (TM / 2) * 16 * ROWB <= LDS_ROWS) ? TM / 2 : 1);
-  constexpr int ROWS = TMP * 16, ITER = (ROWS + RPI - 1) / RPI, NPASS = TM / TMP;
-  constexpr bool PRE = TM * TN * 4 + NPASS * ITER * 4 + 48 <= VCAP;     // accumulators + residual chunks + working set
+  // 16-row groups per pass: as many as the staging LDS holds -- unless a smaller pass is what lets the residual chunks be
+  // requested ahead of the stores within the register cap (PRE: all of them up front; ROLL: the next pass's, two rolling sets)
+  constexpr int ACC = TM * TN * 4;
+  constexpr auto iters = [](int tmp) { return (tmp * 16 + RPI - 1) / RPI; };
+  constexpr auto fits = [](int tmp) { return tmp >= 1 && TM % tmp == 0 && NW * tmp * 16 * ROWB <= LDS_ROWS; };
+  constexpr auto pre_ok = [](int tmp) { return ACC + (TM / tmp) * ((tmp * 16 + RPI - 1) / RPI) * 4 + 48 <= VCAP; };
+  constexpr auto roll_ok = [](int tmp) { return TM / tmp > 1 && ACC + 2 * ((tmp * 16 + RPI - 1) / RPI) * 4 + 40 <= VCAP; };
+  constexpr int T_LDS = fits(TM) ? TM : (fits(TM / 2) ? TM / 2 : 1);
+  constexpr int TMP = pre_ok(T_LDS) ? T_LDS : (roll_ok(T_LDS) ? T_LDS : ((T_LDS > 1 && roll_ok(T_LDS / 2) && fits(T_LDS / 2)) ? T_LDS / 2 : ((T_LDS > 1 && roll_ok(1)) ? 1 : T_LDS)));
+  constexpr int ROWS = TMP * 16, ITER = iters(TMP), NPASS = TM / TMP;
+  constexpr bool PRE = pre_ok(TMP);
+  constexpr bool ROLL = !PRE && roll_ok(TMP);
   static_assert(OCOLS % 8 == 0 && NW * 16 * ROWB <= LDS_ROWS, "epilogue staging");
   const int c16 = lane & 15, g4 = lane >> 4;
   const float scale = p.scale;
@@ -85,6 +94,16 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
         }
     }
   }
+  uint4 rcur[ROLL ? ITER : 1], rnext[ROLL ? ITER : 1];
+  auto roll_load = [&](uint4 (&dst)[ROLL ? ITER : 1], int ps) {
+#pragma unroll
+    for (int it = 0; it < (ROLL ? ITER : 1); ++it) {
+      const int row = it * RPI + lr, m = m0 + pm0 + ps * ROWS + row;
+      dst[it] = make_uint4(0, 0, 0, 0);
+      if (lane_on && row < ROWS && m < M) dst[it] = *(const uint4*)((const _Float16*)p.residual + (int64_t)m * ldo + ncol);
+    }
+  };
+  if constexpr (ROLL) { if (p.residual) roll_load(rcur, 0); }
   __syncthreads();                                           // every wave is done reading the staging tiles
   if constexpr (!VECPRE) {
     if (tid < BN / 4) { *(float4*)(lvec + tid * 4) = vb; *(float4*)(lvec + BN + tid * 4) = vc; }
@@ -129,6 +148,7 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
     // read back row-wise (same wave wrote it: no block barrier needed, only the LDS write->read ordering)
     __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
+    if constexpr (ROLL) { if (p.residual && ps + 1 < NPASS) roll_load(rnext, ps + 1); }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int row = it * RPI + lr, m = m0 + pm0 + ps * ROWS + row;
@@ -136,13 +156,18 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
       uint4 raw = *(const uint4*)(wl + row * ROWB + lc * 16);
       const int64_t oi = (int64_t)m * ldo + ncol;
       if (p.residual) {
-        const h16x8 rr = PRE ? __builtin_bit_cast(h16x8, resid[PRE ? ps * ITER + it : 0]) : *(const h16x8*)((const _Float16*)p.residual + oi);
+        const h16x8 rr = PRE ? __builtin_bit_cast(h16x8, resid[PRE ? ps * ITER + it : 0])
+                       : ROLL ? __builtin_bit_cast(h16x8, rcur[ROLL ? it : 0]) : *(const h16x8*)((const _Float16*)p.residual + oi);
         h16x8 hv = __builtin_bit_cast(h16x8, raw);
 #pragma unroll
         for (int e = 0; e < 8; ++e) hv[e] = (_Float16)((float)hv[e] + (float)rr[e]);
         raw = __builtin_bit_cast(uint4, hv);
       }
       *(uint4*)((_Float16*)p.out + oi) = raw;
+    }
+    if constexpr (ROLL) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) rcur[it] = rnext[it];
     }
     __builtin_amdgcn_wave_barrier();                         // (LDS is in order per wave: the next pass may overwrite)
   }

@@ -14,15 +14,16 @@ w = O.pack_conv_weight(torch.randn(N, C, KH, KH) * (C * KH * KH) ** -0.5, dt).cu
 Ho, Wo = (2 * H, 2 * W) if up else (H, W)
 out = torch.empty(B * Ho * Wo, N // 2 if act == 2 else N, dtype=dt, device="cuda")
 bias = torch.zeros(N, device="cuda")
+res = torch.randn_like(out) if os.environ.get("BENCH_RES") == "1" else None
 for _ in range(3):
-    O.igemm(x, w, out, B, H, W, C, N, KH=KH, upsample=up, bias=bias, act=act)
+    O.igemm(x, w, out, B, H, W, C, N, KH=KH, upsample=up, bias=bias, act=act, residual=res)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    O.igemm(x, w, out, B, H, W, C, N, KH=KH, upsample=up, bias=bias, act=act)
+    O.igemm(x, w, out, B, H, W, C, N, KH=KH, upsample=up, bias=bias, act=act, residual=res)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 fl = 2.0 * B * Ho * Wo * N * KH * KH * C
-print(f"B{B} {H}x{W} C{C} N{N} k{KH} up{up} act{act}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s")
+print(f"B{B} {H}x{W} C{C} N{N} k{KH} up{up} act{act} res{int(res is not None)}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TF/s")
