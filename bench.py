@@ -51,7 +51,7 @@ def cpu_baseline():
 
 # profiles/r02_igemm_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) of the igemm family over the 12 UNet evaluations of
 # `bench.py --roofline-only`, per evaluation
-MEASURED_IGEMM_TRAFFIC_BYTES = 34.85e9
+MEASURED_IGEMM_TRAFFIC_BYTES = 34.23e9
 
 
 def main():
