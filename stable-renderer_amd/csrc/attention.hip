@@ -751,7 +751,9 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
         //  and slower: 725 us.  With the vector phase compiled out it takes 481 us, without the staging 593 us: the vector work of one
         //  wave does NOT hide under the partner's MFMAs, because every MFMA holds the SIMD's vector issue port for 8 of its 16 cycles;
         //  both forms share the issue floor of ~1430 cycles per pair of wave-tiles (= 330 us), and what is left to remove is issue
-        //  cost itself: 32x32x16 MFMAs (half the holds per FLOP) and fewer max / pack instructions -- a different fragment layout.)
+        //  cost itself: 32x32x16 MFMAs (half the holds per FLOP) and fewer max / pack instructions -- a different fragment layout.
+        //  Also parity clean and slower: waves 4-7 taking the per-tile barrier in the middle of their iteration (ring of 4 slots), so
+        //  that the two waves of a SIMD run half a tile apart: 686 vs 648 us.)
         static const int stg = getenv("SR_ATTN_STG") ? atoi(getenv("SR_ATTN_STG")) : 1;           // A-B aid: tiles per barrier
         if (nthr == 512 && lazy && ktb == 4 && stg == 2) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 4, 2, 2>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 4, 2, 2>(*a, st);
         if (nthr == 512 && lazy && ktb == 4 && stg == 3) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 4, 2, 3>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 4, 2, 3>(*a, st);
