@@ -320,6 +320,9 @@ __global__ __launch_bounds__(256, MB) void attn_kernel(const sr_attention_args p
 //     tile's maximum exceeds the current shift by more than 2^TAU -- probabilities stay <= 256, comfortably inside fp16 / fp32
 //     accumulation -- and always after the first tile; softmax is shift invariant, so only rounding differs from the exact-max form;
 //   * the two cross-row max reductions are v_permlane16_swap / v_permlane32_swap (VALU) instead of ds_bpermute round trips.
+#ifndef SR_ATTN_TRACE
+#define SR_ATTN_TRACE 0      // development only: every wave accumulates the shader-clock time of the three parts of an iteration
+#endif
 #ifndef SR_ATTN_DBG
 #define SR_ATTN_DBG 0        // development only: 1 = no per-tile barrier / loads (timing of the compute alone; wrong results),
 #endif                       // 2 = exp replaced by a multiply, 3 = both
@@ -573,6 +576,9 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   qk(sA, 0);
   rowmax(sA, 0, NT == 1);
 
+#if SR_ATTN_TRACE
+  long long trc[3] = {0, 0, 0};
+#endif
   int slot = 0;                                              // ring slot of tile t
   // STEADY: tile t+1 exists and is a full tile (compile-time straight-line body); otherwise wave-uniform run-time flags
   auto iter = [&](f32x4 (&sc)[KTB][QT], f32x4 (&sn)[KTB][QT], int t, auto steady_tag) {
@@ -580,11 +586,18 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
     const bool has_next = STEADY || t + 1 < NT, mask = !STEADY && t + 2 == NT;
     const int s1 = slot == NS - 1 ? 0 : slot + 1;            // slot of tile t+1
     const int s2 = slot + 2 * STG >= NS ? slot + 2 * STG - NS : slot + 2 * STG;   // slot of tile t + 2*STG (its old tile: t - STG)
+#if SR_ATTN_TRACE
+    const long long tr0 = clock64();
+#endif
     if (t > 0 && !(SR_ATTN_DBG & 1)) {
       if (STG == 1 || t % STG == 0) __syncthreads();         // every wave is past iteration t-1 (see the slot timing above)
       if (t + 2 * STG < NT) lstore(s2);
       if (t + 2 * STG + 1 < NT) gload((t + 2 * STG + 1) * KV);
     }
+#if SR_ATTN_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const long long tr1 = clock64();
+#endif
     uint4 pf[KTB / 2][QT];
     // alpha of tile t (from the previous iteration's rowmax); once the running maxima settle every alpha is exactly 1 and
     // the 12 packed multiplies are skipped (wave-uniform branch ahead of the pipelined body, which stays one block)
@@ -622,6 +635,10 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
       }
     }
+#if SR_ATTN_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const long long tr2 = clock64();
+#endif
     pv(pf, slot);
     if (has_next) rowmax(sn, (t + 1) * KV, mask);
     if constexpr (STEADY) {
@@ -631,6 +648,11 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 1);
       }
     }
+#if SR_ATTN_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const long long tr3 = clock64();
+    trc[0] += tr1 - tr0; trc[1] += tr2 - tr1; trc[2] += tr3 - tr2;
+#endif
     slot = s1;
   };
   int t = 0;
@@ -643,6 +665,12 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
     else       iter(sB, sA, t, std::false_type{});
   }
 
+#if SR_ATTN_TRACE
+  if (lane == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0) {
+    long long* o_ = (long long*)((_Float16*)p.k + (int64_t)p.Bk * p.Tk * p.k_stride) + (blockIdx.x * (NTHR / 64) + wv) * 4;   // rows the caller left behind K (tools/trace_attn.py)
+    o_[0] = trc[0]; o_[1] = trc[1]; o_[2] = trc[2]; o_[3] = NT;
+  }
+#endif
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float l;
