@@ -696,6 +696,305 @@ __global__ __launch_bounds__(NTHR, MB) void attn_pipe_kernel(const sr_attention_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Occupancy variant for the d = 40 self-attention (fp16, 32 < d < 48, d % 16 != 0, long Tk): what the timelines of the pipelined
+// kernel above asked for -- fewer vector-issue cycles per score and more waves per SIMD instead of an in-wave software pipeline.
+//   * 32x32x16 MFMAs: S^T tiles of 32 keys x 32 queries (16 accumulator registers), QK^T over three 16-channel steps (48 padded
+//     channels instead of 64), O^T as two 32-row tiles; 14 MFMAs per 64 keys x 32 queries instead of 28, each holding the vector
+//     issue port for the same 8 cycles.  The accumulators of S^T are again the B operand of the PV product: lane (q = lane & 31,
+//     g = lane >> 5) register i holds key (i/4)*8 + 4g + i%4 of its query, so the 16-key step s' of a tile packs registers
+//     8s'..8s'+7 and V^T is read in the same key order (two 8-byte pieces per lane).
+//   * one S set (no QK^T(t+1) | exp(t) overlap inside a wave), K / V^T tiles brought in by LDS-DMA (no staging registers):
+//     <= 168 registers, so three 4-wave workgroups share a CU and fill each other's LDS / dependency waits; they are not
+//     synchronised with each other, so the SIMD partners drift apart by themselves.
+//   * shift-in-the-MFMA softmax as above (channel d of K = 1.0, of Q = -m, lazy moves), the denominator from the ones row d of V^T.
+// One barrier per tile: [wait my DMA of tile t+1] [barrier: tile t+1 visible, everyone is done with tile t] [DMA of tile t+2 into
+// the buffer of tile t] [compute tile t+1].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Row r of a 32-key S^T tile holds key pi(r): the rows lane group g packs for PV step s' -- {16s' + 4g + x, 16s' + 8 + 4g + x},
+// x = 0..3 -- are keys 8(2s'+g) .. +7, i.e. ONE 16-byte chunk of a V^T row (the K rows are simply staged in that order).
+__device__ __forceinline__ int attn32_pi(int r) { return ((r >> 4) * 2 + ((r >> 2) & 1)) * 8 + ((r >> 3) & 1) * 4 + (r & 3); }
+template <int NWAVE, int MINW>
+__global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_attention_args p) {
+  using T = _Float16;
+  constexpr int NTHR = NWAVE * 64, KV = 64, KROW = 128, VROW = 128;
+  constexpr int K_BYTES = KV * KROW, V_BYTES = 64 * VROW, TILE_B = K_BYTES + V_BYTES;    // 8 KB + 8 KB
+  constexpr int KI = (KV * 8 + NTHR - 1) / NTHR, VI = (64 * 8 + NTHR - 1) / NTHR;      // 16-byte slots per thread and tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q32 = lane & 31, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int bk = p.Bk == 1 ? 0 : b;
+  const int d = p.d, Tk = p.Tk;
+  const int q0 = blockIdx.x * (NWAVE * 32) + wv * 32;
+  const int NT = (Tk + KV - 1) / KV;
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  // ---- Q fragments (B operand): lane (q, g) holds channels 16j + 8g .. +7 of its query, pre-scaled; channel d carries -m
+  uint4 qf[3];
+  {
+    const _Float16 hs = (_Float16)sl2;
+    const h16x8 hsv = {hs, hs, hs, hs, hs, hs, hs, hs};
+    const int q = q0 + q32;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ch = 16 * j + 8 * g;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < p.Tq && ch < d) v = *(const uint4*)((const T*)p.q + ((int64_t)b * p.Tq + q) * p.q_stride + h * d + ch);
+      qf[j] = __builtin_bit_cast(uint4, __builtin_bit_cast(h16x8, v) * hsv);
+    }
+  }
+  const int m_j = d >> 4, m_g = (d & 15) >> 3;               // where channel d sits: k-step d/16, lane group (d%16)/8, element 0
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float mrow = 0.f;
+  constexpr float TAU = 8.0f;
+
+  // ---- staging by LDS-DMA: 16-byte slot sigma of a tile = (row, s); the slot holds logical chunk c = s ^ ((row >> 1) & 7)
+  // (the swizzle that makes the 32-row fragment reads conflict free, applied on the source side); padding chunks and rows are
+  // constants written once into both buffers and never overwritten (their lanes are masked out of the DMA)
+  const char* kbase = (const char*)((const T*)p.k + (int64_t)bk * Tk * p.k_stride + h * d);
+  const char* vbase = (const char*)((const T*)p.vt + ((int64_t)bk * p.heads + h) * (int64_t)d * p.ldt);
+  const unsigned krow_b = (unsigned)p.k_stride * 2u, vrow_b = (unsigned)p.ldt * 2u;
+  int k_key[KI]; unsigned k_off[KI]; bool k_ok[KI];
+  unsigned v_off[VI]; int v_c8[VI]; bool v_ok[VI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int sg = i * NTHR + tid, row = sg >> 3, sl = sg & 7, c = sl ^ ((row >> 1) & 7);
+    k_key[i] = (row & 32) + attn32_pi(row & 31); k_off[i] = (unsigned)c * 16u; k_ok[i] = sg < KV * 8 && c * 8 < d;
+  }
+#pragma unroll
+  for (int i = 0; i < VI; ++i) {
+    const int sg = i * NTHR + tid, row = sg >> 3, sl = sg & 7, c = sl ^ ((row >> 1) & 7);
+    v_off[i] = (unsigned)row * vrow_b; v_c8[i] = c * 8; v_ok[i] = sg < 64 * 8 && row < d;
+  }
+#pragma unroll
+  for (int bf = 0; bf < 2; ++bf) {
+    char* bs = smem + bf * TILE_B;
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int sg = i * NTHR + tid, row = sg >> 3, sl = sg & 7, c = sl ^ ((row >> 1) & 7);
+      if (sg < KV * 8 && c * 8 >= d) *(uint4*)(bs + sg * 16) = (c * 8 == d) ? make_uint4(0x00003C00u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int sg = i * NTHR + tid, row = sg >> 3;
+      if (sg < 64 * 8 && row >= d)
+        *(uint4*)(bs + K_BYTES + sg * 16) = (row == d) ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(sr_lds_addr(smem));
+  auto dma = [&](int u, int bf) {                            // tile u -> buffer bf
+    const int k0 = u * KV;
+    const unsigned m0keep = sr_m0_save();
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int key = min(k0 + k_key[i], Tk - 1);            // rows past Tk: any valid row, their scores are masked
+      const unsigned la = lds0 + bf * TILE_B + (i * NTHR + wv * 64) * 16;
+      if (k_ok[i]) sr_glds16_asm_saddr((unsigned)key * krow_b + k_off[i], kbase, la);
+    }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int key = min(k0 + v_c8[i], p.ldt - 8);          // columns past Tk meet p = 0
+      const unsigned la = lds0 + bf * TILE_B + K_BYTES + (i * NTHR + wv * 64) * 16;
+      if (v_ok[i]) sr_glds16_asm_saddr(v_off[i] + (unsigned)key * 2u, vbase, la);
+    }
+    sr_m0_restore(m0keep);
+  };
+
+  // ---- fragment read offsets (bytes inside a tile buffer); +32 rows leave (row >> 1) & 7 unchanged, so kt / dt are plain offsets
+  const int swz = (q32 >> 1) & 7;
+  int k_rd[3], v_rd[4];                                      // K: row kt*32 + q32, chunk 2j + g;  V^T: row dt*32 + q32, chunk kt*4 + 2sp + g
+#pragma unroll
+  for (int j = 0; j < 3; ++j) k_rd[j] = q32 * KROW + (((2 * j + g) ^ swz) * 16);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v_rd[c] = q32 * VROW + (((2 * (c & 1) + g + 4 * (c >> 1)) ^ swz) * 16);   // c = kt*2 + sp
+
+#if SR_ATTN_TRACE
+  long long trc[4] = {0, 0, 0, 0};
+#endif
+  auto tile = [&](int t, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+#if SR_ATTN_TRACE
+    const long long a0 = clock64();
+#endif
+    const int bf = t & 1;
+#ifndef SR_A32_DBG
+#define SR_A32_DBG 0          // development only: 1 = no per-tile DMA / barrier (timing of the compute alone), 2 = no exp2
+#endif
+    if (t + 1 < NT && !(SR_A32_DBG & 1)) dma(t + 1, bf ^ 1);
+    const char* cK = smem + bf * TILE_B;
+    const char* cV = cK + K_BYTES;
+    // ---- S^T = K Q^T (two 32-key tiles)
+    f32x16 sacc[2];
+    {
+      uint4 kf[2][3];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) kf[kt][j] = *(const uint4*)(cK + kt * 32 * KROW + k_rd[j]);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, kf[kt][j]), __builtin_bit_cast(h16x8, qf[j]), sacc[kt], 0, 0, 0);
+    }
+#if SR_ATTN_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 0" :: "v"(sacc[0][0]), "v"(sacc[1][15]));
+    const long long a1 = clock64();
+#endif
+    // ---- row max / lazy shift / exp2 / pack
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (t * KV + kt * 32 + attn32_pi((i >> 2) * 8 + 4 * g + (i & 3)) >= Tk) sacc[kt][i] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kt][i]);
+    {
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (t == 0 || mx > TAU) {                                // (per-lane condition, identical in the two lanes of a query)
+      const float mnew = (float)(_Float16)(mrow + mx);       // fp16 representable: the MFMA sees exactly this value
+      const float dl = mnew - mrow;
+      mrow = mnew;
+      const float alpha = __builtin_amdgcn_exp2f(-dl);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[kt][i] -= dl;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+      const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(-mrow));
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j == m_j && g == m_g) qf[j].x = (qf[j].x & 0xffff0000u) | hb;
+    }
+#if SR_ATTN_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const long long a2 = clock64();
+#endif
+    // exp2 / pack of key tile 0, then PV of key tile 0 interleaved with exp2 / pack of key tile 1, then PV of key tile 1.
+    // Step (kt, sp) of lane group g covers keys kt*32 + 8(2sp + g) .. +7 = one 16-byte chunk of a V^T row.
+    uint4 pf[2][2], vf[2][2][2];
+    auto pack = [&](int kt) {
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        h16x8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (_Float16)((SR_A32_DBG & 2) ? sacc[kt][8 * sp + e] * 0.001f : __builtin_amdgcn_exp2f(sacc[kt][8 * sp + e]));
+        pf[kt][sp] = __builtin_bit_cast(uint4, hv);
+      }
+    };
+    auto vread = [&](int kt) {
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) vf[kt][sp][dt] = *(const uint4*)(cV + dt * 32 * VROW + v_rd[kt * 2 + sp]);
+    };
+    auto pvmma = [&](int kt) {
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, vf[kt][sp][dt]), __builtin_bit_cast(h16x8, pf[kt][sp]), o[dt], 0, 0, 0);
+    };
+    vread(0);
+    pack(0);
+    vread(1);
+    __builtin_amdgcn_sched_barrier(0);
+    pvmma(0);
+    pack(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // 4 exp + 2 pack
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pvmma(1);
+#if SR_ATTN_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(o[1][15]));
+    const long long a3 = clock64();
+#endif
+    if (!(SR_A32_DBG & 1)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of tile t+1 have landed
+      __syncthreads();                                       // ... everyone's have, and everyone is done with tile t
+    }
+#if SR_ATTN_TRACE
+    const long long a4 = clock64();
+    trc[0] += a1 - a0; trc[1] += a2 - a1; trc[2] += a3 - a2; trc[3] += a4 - a3;
+#endif
+  };
+
+  dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int NFULL = (Tk % KV) ? NT - 1 : NT;                 // the ragged tail tile (if any) runs the masked body
+  for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
+  if (NFULL < NT) tile(NT - 1, std::true_type{});
+
+#if SR_ATTN_TRACE
+  if (lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0) {
+    long long* o_ = (long long*)((_Float16*)p.k + (int64_t)p.Bk * p.Tk * p.k_stride) + (blockIdx.x * NWAVE + wv) * 5;
+    o_[0] = trc[0]; o_[1] = trc[1]; o_[2] = trc[2]; o_[3] = trc[3]; o_[4] = NT;
+  }
+#endif
+  // ---- output: O^T[dt] register i of lane (q, g) is channel dt*32 + (i/4)*8 + 4g + i%4; the denominator is channel d
+  const int den_i = ((d & 31) >> 3) * 4 + (d & 3), den_g = (d & 7) >> 2, den_dt = d >> 5;
+  float l = 1.f;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (dt == den_dt && i == den_i) l = o[dt][i];
+  l = __shfl(l, den_g * 32 + q32);
+  const float inv = 1.0f / l;
+  const int q = q0 + q32;
+  if (q < p.Tq) {
+    T* orow = (T*)p.o + ((int64_t)b * p.Tq + q) * p.q_stride + h * d;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int di = dt * 32 + i4 * 8 + 4 * g;
+        if (di >= d) continue;
+        h16x4 hv = {(_Float16)(o[dt][4 * i4] * inv), (_Float16)(o[dt][4 * i4 + 1] * inv), (_Float16)(o[dt][4 * i4 + 2] * inv),
+                    (_Float16)(o[dt][4 * i4 + 3] * inv)};
+        *(h16x4*)(orow + di) = hv;
+      }
+  }
+}
+
+template <int NWAVE, int MINW>
+int launch_attn32(const sr_attention_args& a, hipStream_t st) {
+  dim3 grid(sr_cdiv(a.Tq, NWAVE * 32), a.heads, a.B);
+  constexpr int lds = 2 * (64 * 128 + 64 * 128);
+  auto k = attn32_kernel<NWAVE, MINW>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  hipLaunchKernelGGL(k, grid, dim3(NWAVE * 64), lds, st, a);
+  SR_CHECK_LAUNCH("sr_attention");
+  return SR_OK;
+}
+
 template <int DQ, int DT, bool SR, int MB = 2, int NTHR = 256, bool LAZY = false, int KTB = 4, int QT = 2, int STG = 1>
 int launch_pipe(const sr_attention_args& a, hipStream_t st) {
   dim3 grid(sr_cdiv(a.Tq, (NTHR / 64) * 16 * QT), a.heads, a.B);
@@ -783,6 +1082,15 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
         //  Also parity clean and slower: waves 4-7 taking the per-tile barrier in the middle of their iteration (ring of 4 slots), so
         //  that the two waves of a SIMD run half a tile apart: 686 vs 648 us.)
         static const int stg = getenv("SR_ATTN_STG") ? atoi(getenv("SR_ATTN_STG")) : 1;           // A-B aid: tiles per barrier
+        // d = 40 (32 < d < 48, not a multiple of 16): the 32x32-MFMA occupancy kernel, 507-516 vs 647-658 us at B16 T4096 (SR_ATTN_32=0:
+        // the software-pipelined kernel below; 1/2: four waves per workgroup; 3: eight waves, cap 256 registers)
+        static const int a32 = getenv("SR_ATTN_32") ? atoi(getenv("SR_ATTN_32")) : 4;             // A-B aid
+        if (a32 && d > 32 && d < 48 && (d & 15) && (d & 7) == 0) {
+          if (a32 == 1) return launch_attn32<4, 3>(*a, st);
+          if (a32 == 2) return launch_attn32<4, 4>(*a, st);
+          if (a32 == 3) return launch_attn32<8, 2>(*a, st);
+          return launch_attn32<8, 4>(*a, st);
+        }
         if (nthr == 512 && lazy && ktb == 4 && stg == 2) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 4, 2, 2>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 4, 2, 2>(*a, st);
         if (nthr == 512 && lazy && ktb == 4 && stg == 3) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 4, 2, 3>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 4, 2, 3>(*a, st);
         if (nthr == 512 && lazy && ktb == 2 && stg == 4) return (d & 15) ? launch_pipe<2, 3, true, 2, 512, true, 2, 2, 4>(*a, st) : launch_pipe<2, 3, false, 2, 512, true, 2, 2, 4>(*a, st);
@@ -792,6 +1100,9 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
         return (d & 15) ? launch_pipe<2, 3, true>(*a, st) : launch_pipe<2, 3, false>(*a, st);
       }
       if (shortk) return (d & 15) ? launch_short<_Float16, 2, 3, 2, true>(*a, st) : launch_short<_Float16, 2, 3, 2>(*a, st);
+      static const int smb = getenv("SR_ATTN_SIMPLE_MB") ? atoi(getenv("SR_ATTN_SIMPLE_MB")) : 2;   // probe: occupancy of the simple loop
+      if (smb == 3 && (d & 15)) return launch<_Float16, 2, 3, 2, true, 3>(*a, st);
+      if (smb == 4 && (d & 15)) return launch<_Float16, 2, 3, 2, true, 4>(*a, st);
       return (d & 15) ? launch<_Float16, 2, 3, 2, true>(*a, st) : launch<_Float16, 2, 3, 2>(*a, st);
     }
     if (d <= 64) return launch<_Float16, 2, 4, 2>(*a, st);

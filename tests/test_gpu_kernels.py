@@ -332,6 +332,11 @@ def _attn_ref(q, k, v, heads):
     (2, 1, 640, 128, 4, 80),      # two full key tiles, shared K/V, d = 80
     (2, 2, 1024, 64, 2, 48),      # a single key tile, d a multiple of 16 (no ones row)
     (1, 1, 512, 100, 2, 160),     # d = 160
+    # long key sequences at d = 40 (fp16: the 32x32-MFMA occupancy kernel; fp32: the simple loop): ragged queries AND a ragged
+    # last key tile (1000 = 15 x 64 + 40), shared and per-entry K/V
+    (2, 1, 600, 1000, 8, 40),
+    (2, 2, 320, 1000, 4, 40),
+    (1, 1, 256, 4160, 2, 40),     # 65 key tiles: odd tile count through the double buffer
 ])
 def test_attention(ops, dtype, cfg):
     B, Bk, Tq, Tk, heads, d = cfg

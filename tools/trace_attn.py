@@ -17,10 +17,14 @@ vt = torch.randn(1, Cc, ldt, dtype=dt, device="cuda").view(1, heads, d, ldt)
 for _ in range(3):
     O.attention(q, k, vt, heads, Tk=Tk)
 torch.cuda.synchronize()
-tr = kbig[0, Tk:].contiguous().view(torch.int64)[: 64 * 8 * 4].reshape(-1, 4).cpu().numpy()
-tr = tr[tr[:, 3] == (Tk + 63) // 64]
-nt = tr[0, 3]
+a32 = os.environ.get("SR_ATTN_32", "0") != "0"
+ncol = 5 if a32 else 4
+raw = kbig[0, Tk:].contiguous().view(torch.int64)
+tr = raw[: (raw.numel() // ncol) * ncol].reshape(-1, ncol).cpu().numpy()
+tr = tr[tr[:, ncol - 1] == (Tk + 63) // 64]
+nt = tr[0, ncol - 1]
 print("waves traced: %d, tiles per wave: %d" % (len(tr), nt))
-for i, nme in enumerate(["hand-off", "phase A (QK^T | exp)", "phase B (PV | row max)"]):
-    print("  %-24s %7.0f cycles per tile (min %6.0f max %6.0f over waves)" % (nme, tr[:, i].mean() / nt, tr[:, i].min() / nt, tr[:, i].max() / nt))
-print("  total                    %7.0f cycles per tile" % (tr[:, :3].sum(1).mean() / nt))
+names = ["DMA issue + K reads + QK^T", "row max / lazy shift", "exp2 / pack / PV", "vmcnt wait + barrier"] if a32 else ["hand-off", "phase A (QK^T | exp)", "phase B (PV | row max)"]
+for i, nme in enumerate(names):
+    print("  %-28s %7.0f cycles per tile (min %6.0f max %6.0f over waves)" % (nme, tr[:, i].mean() / nt, tr[:, i].min() / nt, tr[:, i].max() / nt))
+print("  total                        %7.0f cycles per tile" % (tr[:, :ncol - 1].sum(1).mean() / nt))
