@@ -15,7 +15,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$R/gpurun_out/pmc_attn/*/*counter_collection.csv") + glob.glob("$R/gpurun_out/pmc_attn/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "attn_pipe_kernel" in r["Kernel_Name"]:
+        if "attn_pipe_kernel" in r["Kernel_Name"] or "attn32_kernel" in r["Kernel_Name"]:
             a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, (v, n) in sorted(agg.items()):
     print(f"{k:32s} {v/n:16.0f}  (n={n})")
