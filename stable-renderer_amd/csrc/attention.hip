@@ -717,12 +717,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Row r of a 32-key S^T tile holds key pi(r): the rows lane group g packs for PV step s' -- {16s' + 4g + x, 16s' + 8 + 4g + x},
 // x = 0..3 -- are keys 8(2s'+g) .. +7, i.e. ONE 16-byte chunk of a V^T row (the K rows are simply staged in that order).
 __device__ __forceinline__ int attn32_pi(int r) { return ((r >> 4) * 2 + ((r >> 2) & 1)) * 8 + ((r >> 3) & 1) * 4 + (r & 3); }
-template <int NWAVE, int MINW>
+// KS: 16-channel steps of QK^T (covers d channels + the shift channel d), OT: 32-row tiles of O^T (covers d rows + the ones row d)
+template <int NWAVE, int MINW, int KS = 3, int OT = 2>
 __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_attention_args p) {
   using T = _Float16;
-  constexpr int NTHR = NWAVE * 64, KV = 64, KROW = 128, VROW = 128;
-  constexpr int K_BYTES = KV * KROW, V_BYTES = 64 * VROW, TILE_B = K_BYTES + V_BYTES;    // 8 KB + 8 KB
-  constexpr int KI = (KV * 8 + NTHR - 1) / NTHR, VI = (64 * 8 + NTHR - 1) / NTHR;      // 16-byte slots per thread and tile
+  constexpr int NTHR = NWAVE * 64, KV = 64, KCH = (2 * KS <= 8) ? 8 : 16, KROW = KCH * 16, VROW = 128, VR = OT * 32;
+  constexpr int K_BYTES = KV * KROW, V_BYTES = VR * VROW, TILE_B = K_BYTES + V_BYTES;
+  constexpr int KI = (KV * KCH + NTHR - 1) / NTHR, VI = (VR * 8 + NTHR - 1) / NTHR;    // 16-byte slots per thread and tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -735,13 +736,13 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
   const float sl2 = p.scale * 1.4426950408889634f;
 
   // ---- Q fragments (B operand): lane (q, g) holds channels 16j + 8g .. +7 of its query, pre-scaled; channel d carries -m
-  uint4 qf[3];
+  uint4 qf[KS];
   {
     const _Float16 hs = (_Float16)sl2;
     const h16x8 hsv = {hs, hs, hs, hs, hs, hs, hs, hs};
     const int q = q0 + q32;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < KS; ++j) {
       const int ch = 16 * j + 8 * g;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (q < p.Tq && ch < d) v = *(const uint4*)((const T*)p.q + ((int64_t)b * p.Tq + q) * p.q_stride + h * d + ch);
@@ -749,9 +750,9 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
     }
   }
   const int m_j = d >> 4, m_g = (d & 15) >> 3;               // where channel d sits: k-step d/16, lane group (d%16)/8, element 0
-  f32x16 o[2];
+  f32x16 o[OT];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < OT; ++dt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   float mrow = 0.f;
@@ -767,26 +768,26 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
   unsigned v_off[VI]; int v_c8[VI]; bool v_ok[VI];
 #pragma unroll
   for (int i = 0; i < KI; ++i) {
-    const int sg = i * NTHR + tid, row = sg >> 3, sl = sg & 7, c = sl ^ ((row >> 1) & 7);
-    k_key[i] = (row & 32) + attn32_pi(row & 31); k_off[i] = (unsigned)c * 16u; k_ok[i] = sg < KV * 8 && c * 8 < d;
+    const int sg = i * NTHR + tid, row = sg / KCH, sl = sg - row * KCH, c = (sl & ~7) | ((sl & 7) ^ ((row >> 1) & 7));
+    k_key[i] = (row & 32) + attn32_pi(row & 31); k_off[i] = (unsigned)c * 16u; k_ok[i] = sg < KV * KCH && c * 8 < d;
   }
 #pragma unroll
   for (int i = 0; i < VI; ++i) {
     const int sg = i * NTHR + tid, row = sg >> 3, sl = sg & 7, c = sl ^ ((row >> 1) & 7);
-    v_off[i] = (unsigned)row * vrow_b; v_c8[i] = c * 8; v_ok[i] = sg < 64 * 8 && row < d;
+    v_off[i] = (unsigned)row * vrow_b; v_c8[i] = c * 8; v_ok[i] = sg < VR * 8 && row < d;
   }
 #pragma unroll
   for (int bf = 0; bf < 2; ++bf) {
     char* bs = smem + bf * TILE_B;
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
-      const int sg = i * NTHR + tid, row = sg >> 3, sl = sg & 7, c = sl ^ ((row >> 1) & 7);
-      if (sg < KV * 8 && c * 8 >= d) *(uint4*)(bs + sg * 16) = (c * 8 == d) ? make_uint4(0x00003C00u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
+      const int sg = i * NTHR + tid, row = sg / KCH, sl = sg - row * KCH, c = (sl & ~7) | ((sl & 7) ^ ((row >> 1) & 7));
+      if (sg < KV * KCH && c * 8 >= d) *(uint4*)(bs + sg * 16) = (c * 8 == d) ? make_uint4(0x00003C00u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
       const int sg = i * NTHR + tid, row = sg >> 3;
-      if (sg < 64 * 8 && row >= d)
+      if (sg < VR * 8 && row >= d)
         *(uint4*)(bs + K_BYTES + sg * 16) = (row == d) ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u) : make_uint4(0, 0, 0, 0);
     }
   }
@@ -811,9 +812,9 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
 
   // ---- fragment read offsets (bytes inside a tile buffer); +32 rows leave (row >> 1) & 7 unchanged, so kt / dt are plain offsets
   const int swz = (q32 >> 1) & 7;
-  int k_rd[3], v_rd[4];                                      // K: row kt*32 + q32, chunk 2j + g;  V^T: row dt*32 + q32, chunk kt*4 + 2sp + g
+  int k_rd[KS], v_rd[4];                                      // K: row kt*32 + q32, chunk 2j + g;  V^T: row dt*32 + q32, chunk kt*4 + 2sp + g
 #pragma unroll
-  for (int j = 0; j < 3; ++j) k_rd[j] = q32 * KROW + (((2 * j + g) ^ swz) * 16);
+  for (int j = 0; j < KS; ++j) k_rd[j] = q32 * KROW + ((((2 * j + g) & ~7) | (((2 * j + g) & 7) ^ swz)) * 16);
 #pragma unroll
   for (int c = 0; c < 4; ++c) v_rd[c] = q32 * VROW + (((2 * (c & 1) + g + 4 * (c >> 1)) ^ swz) * 16);   // c = kt*2 + sp
 
@@ -835,17 +836,17 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
     // ---- S^T = K Q^T (two 32-key tiles)
     f32x16 sacc[2];
     {
-      uint4 kf[2][3];
+      uint4 kf[2][KS];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) kf[kt][j] = *(const uint4*)(cK + kt * 32 * KROW + k_rd[j]);
+        for (int j = 0; j < KS; ++j) kf[kt][j] = *(const uint4*)(cK + kt * 32 * KROW + k_rd[j]);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < KS; ++j)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
           sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, kf[kt][j]), __builtin_bit_cast(h16x8, qf[j]), sacc[kt], 0, 0, 0);
@@ -882,12 +883,12 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[kt][i] -= dl;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < OT; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
       const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(-mrow));
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < KS; ++j)
         if (j == m_j && g == m_g) qf[j].x = (qf[j].x & 0xffff0000u) | hb;
     }
 #if SR_ATTN_TRACE
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
 #endif
     // exp2 / pack of key tile 0, then PV of key tile 0 interleaved with exp2 / pack of key tile 1, then PV of key tile 1.
     // Step (kt, sp) of lane group g covers keys kt*32 + 8(2sp + g) .. +7 = one 16-byte chunk of a V^T row.
-    uint4 pf[2][2], vf[2][2][2];
+    uint4 pf[2][2], vf[2][2][OT];
     auto pack = [&](int kt) {
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
@@ -910,13 +911,13 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) vf[kt][sp][dt] = *(const uint4*)(cV + dt * 32 * VROW + v_rd[kt * 2 + sp]);
+        for (int dt = 0; dt < OT; ++dt) vf[kt][sp][dt] = *(const uint4*)(cV + dt * 32 * VROW + v_rd[kt * 2 + sp]);
     };
     auto pvmma = [&](int kt) {
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < OT; ++dt)
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, vf[kt][sp][dt]), __builtin_bit_cast(h16x8, pf[kt][sp]), o[dt], 0, 0, 0);
     };
     vread(0);
@@ -926,9 +927,9 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
     pvmma(0);
     pack(1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * OT; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // 4 exp + 2 pack
+      __builtin_amdgcn_sched_group_barrier(0x002, (24 + 2 * OT - 1) / (2 * OT), 0);     // its share of the 16 exp + 8 pack
     }
     __builtin_amdgcn_sched_barrier(0);
     pvmma(1);
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
   const int den_i = ((d & 31) >> 3) * 4 + (d & 3), den_g = (d & 7) >> 2, den_dt = d >> 5;
   float l = 1.f;
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < OT; ++dt)
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       if (dt == den_dt && i == den_i) l = o[dt][i];
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
   if (q < p.Tq) {
     T* orow = (T*)p.o + ((int64_t)b * p.Tq + q) * p.q_stride + h * d;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < OT; ++dt)
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
         const int di = dt * 32 + i4 * 8 + 4 * g;
@@ -986,11 +987,11 @@ __global__ __launch_bounds__(NWAVE * 64, MINW) void attn32_kernel(const sr_atten
   }
 }
 
-template <int NWAVE, int MINW>
+template <int NWAVE, int MINW, int KS = 3, int OT = 2>
 int launch_attn32(const sr_attention_args& a, hipStream_t st) {
   dim3 grid(sr_cdiv(a.Tq, NWAVE * 32), a.heads, a.B);
-  constexpr int lds = 2 * (64 * 128 + 64 * 128);
-  auto k = attn32_kernel<NWAVE, MINW>;
+  constexpr int lds = 2 * (64 * ((2 * KS <= 8) ? 128 : 256) + OT * 32 * 128);
+  auto k = attn32_kernel<NWAVE, MINW, KS, OT>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   hipLaunchKernelGGL(k, grid, dim3(NWAVE * 64), lds, st, a);
@@ -1107,6 +1108,15 @@ extern "C" int sr_attention(const sr_attention_args* a, void* stream) {
       if (smb == 3 && (d & 15)) return launch<_Float16, 2, 3, 2, true, 3>(*a, st);
       if (smb == 4 && (d & 15)) return launch<_Float16, 2, 3, 2, true, 4>(*a, st);
       return (d & 15) ? launch<_Float16, 2, 3, 2, true>(*a, st) : launch<_Float16, 2, 3, 2>(*a, st);
+    }
+    // wider heads with long key sequences (SDXL d = 64 at 64x64 / 32x32, SD1.5 d = 80 at 32x32): the same occupancy kernel with more
+    // channel steps / output tiles, 165-168 registers -> three waves per SIMD.  d = 80, B16 T1024 h8: 64.7 vs 91.9 us for the simple
+    // loop; d = 64, B16 T4096 h10: 961 vs 1206 us, B16 T1024 h20: 150 vs 186 us.  (A 128-register cap spills: 2x slower.)
+    // SR_ATTN_32W: 0 = the simple loop, 1 = four waves per workgroup, 2 = eight; default: 1 for d = 80, 2 for d = 64
+    static const int a32w = getenv("SR_ATTN_32W") ? atoi(getenv("SR_ATTN_32W")) : -1;
+    if (a32w && a->Tk >= 512) {
+      if (d == 64) return a32w == 1 ? launch_attn32<4, 3, 5, 3>(*a, st) : launch_attn32<8, 2, 5, 3>(*a, st);
+      if (d == 80) return a32w == 2 ? launch_attn32<8, 2, 6, 3>(*a, st) : launch_attn32<4, 3, 6, 3>(*a, st);
     }
     if (d <= 64) return launch<_Float16, 2, 4, 2>(*a, st);
     if (d <= 80) return shortk ? launch_short<_Float16, 3, 5, 2>(*a, st) : launch<_Float16, 3, 5, 2>(*a, st);

@@ -337,6 +337,9 @@ def _attn_ref(q, k, v, heads):
     (2, 1, 600, 1000, 8, 40),
     (2, 2, 320, 1000, 4, 40),
     (1, 1, 256, 4160, 2, 40),     # 65 key tiles: odd tile count through the double buffer
+    (2, 1, 600, 1000, 4, 80),     # wider heads, long ragged key sequences (d = 80: SD1.5 32x32 level; d = 64: SDXL)
+    (2, 2, 320, 1024, 4, 64),
+    (1, 1, 200, 1500, 2, 64),
 ])
 def test_attention(ops, dtype, cfg):
     B, Bk, Tq, Tk, heads, d = cfg
