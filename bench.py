@@ -2,8 +2,10 @@
 
 A "step" = one bake call = 8 views: rasterise 8 frames -> EngineData -> 20 denoise steps (UNet cond+uncond, B=16, with
 per-step latent overlap and K/V injection) -> VAE decode 8 x 512^2 -> corr-map update.  Inputs (meshes, textures,
-weights) are resident in HBM before the timed region.  N>1: one process per GPU, every rank runs its own 8-view call
-(weak scaling, no data-path collective); value = all frames / max-over-ranks time.
+weights) are resident in HBM before the timed region.  N>1 (one process per GPU): by default ONE 8-view group is view-sharded over the
+ranks (--mode shard: per-step latent all-gather + per-block K/V-source broadcast over RCCL; strong scaling, value = the group's
+frames / max-over-ranks time) and the replica figure (every rank its own 8-view group, weak scaling, no data-path collective) is
+measured after it and printed beside it as `replicas`; --mode replica makes the replicas the headline.
 """
 import argparse
 import json
@@ -49,9 +51,21 @@ def cpu_baseline():
                       "scaled x4.08 to 512^2; extrapolated per view, overlap step / raster excluded (<0.1%%)" % (t_unet, t_vae256)}
 
 
-# profiles/r02_igemm_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) of the igemm family over the 12 UNet evaluations of
-# `bench.py --roofline-only`, per evaluation
-MEASURED_IGEMM_TRAFFIC_BYTES = 34.23e9
+def recorded_igemm_traffic(lib_hash):
+    """HBM-side bytes of the igemm family per UNet evaluation: (2 x FETCH_SIZE + WRITE_SIZE) from the two --pmc passes of
+    `bench.py --roofline-only` (tools/profile_round.sh -> profiles/rNN_igemm_traffic.json).  PMC counters cannot be read from
+    inside the process, so this is a RECORDED figure: it is quoted only when the newest record was taken on kernels with the
+    source hash of the library loaded now, otherwise (None, file)."""
+    import glob
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_igemm_traffic.json")))
+    if not recs:
+        return None, None
+    with open(recs[-1]) as f:
+        rec = json.load(f)
+    name = os.path.relpath(recs[-1], ROOT)
+    if rec.get("source_hash") != lib_hash or rec.get("hbm_bytes_per_eval") is None:
+        return None, name
+    return float(rec["hbm_bytes_per_eval"]), name
 
 
 def main():
@@ -71,9 +85,12 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="bake calls in flight on each GPU (pipeline.InflightCalls: one host thread + HIP stream + launch plans per "
                          "slot, RNG draws and corr-map updates kept in call order -> same results as 1); 1 = the plain call loop")
-    ap.add_argument("--mode", default="replica", choices=["replica", "shard"],
-                    help="replica: every GPU bakes its own 8-view group (weak scaling, no collective); shard: ONE 8-view group "
-                         "split over the GPUs with the latent all-gather / K,V-source broadcast over RCCL (strong scaling)")
+    ap.add_argument("--mode", default=None, choices=["replica", "shard"],
+                    help="shard (default when launched with more than one rank): ONE 8-view group split over the GPUs -- one view "
+                         "per GPU at N = 8 -- with the per-step latent all-gather and the per-block K/V-source broadcast over RCCL "
+                         "(strong scaling; the replica figure is measured after it and printed beside it as `replicas`); "
+                         "replica (default on one GPU): every GPU bakes its own 8-view group (weak scaling, no collective)")
+    ap.add_argument("--no-replicas-beside", action="store_true", help="shard mode: skip the replica measurement that follows it")
     ap.add_argument("--workload", default="sd15-512", choices=["sd15-512", "sdxl-1024"],
                     help="sd15-512: the configuration BASELINE.json's metric is quoted on (default); sdxl-1024: BASELINE config 5, "
                          "the SDXL base UNet (2.57 B parameters) at 1024x1024 through the same raster / overlap / K-V injection / "
@@ -82,6 +99,8 @@ def main():
                     help="attach the depth + normal ControlNet pair driven by the G-buffers (BASELINE config 4's composition)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.mode is None:
+        a.mode = "shard" if world > 1 else "replica"
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -101,8 +120,16 @@ def main():
     from stable_renderer_amd.pipeline import build_sd15_pipeline
     dtype = torch.float16 if a.dtype == "f16" else torch.float32
     shard = None
-    if a.mode == "shard" and world > 1:
+    if a.mode == "shard" and (world > 1 or os.environ.get("SR_SHARD_FORCE") == "1"):
         from stable_renderer_amd.parallel import ViewShard
+        if world == 1 and dist is None:                       # forced one-rank rehearsal: the collectives need a group to run in
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend, rank=0, world_size=1)
         shard = ViewShard(a.views)
     controls = [("depth", 1.0), ("normal", 1.0)] if a.controlnets else None     # BASELINE config 4's pair (miku-control.json)
     sdxl = a.workload == "sdxl-1024"
@@ -209,13 +236,15 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         peak = 2500.0 if a.dtype == "f16" else 157.3
+        traffic, traffic_file = None, None
+        if a.dtype == "f16" and a.views == 8 and shard is None and not a.controlnets and not sdxl:
+            traffic, traffic_file = recorded_igemm_traffic(L.lib().sr_source_hash().decode())
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm family: igemm_kernel tiles + conv3p_kernel (implicit-GEMM conv/linear, all %d launches of one UNet eval, B=%d)" % (sub.n, (a.views // world if shard is not None else a.views) * 2),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 # HBM-side bytes of these launches per UNet evaluation from the FETCH_SIZE (x2, gfx950) + WRITE_SIZE PMC passes of
-                # this very replay (tools/profile_round.sh -> profiles/r02_igemm_traffic.json); PMC cannot be collected from
-                # inside the process, so the figure is the recorded one and only quoted for the configuration it was measured on
-                "traffic": MEASURED_IGEMM_TRAFFIC_BYTES if (a.dtype == "f16" and a.views == 8 and shard is None and not a.controlnets and not sdxl) else None,
+                # this very replay: recorded_igemm_traffic() -- null unless the record matches the loaded kernels
+                "traffic": traffic, "traffic_recorded_in": traffic_file,
                 "algorithmic_bytes": sub.igemm_bytes(),
                 "launches": sub.n, "avg_launch_us": round(ms * 1e3 / max(sub.n, 1), 2), "flops_per_eval": flops}
         full = pipe.runner._plan["flops"]
@@ -227,6 +256,27 @@ def main():
         ms_full = e0.elapsed_time(e1) / reps
         roof["unet_eval_ms"] = round(ms_full, 3)
         roof["unet_eval_tflops"] = round(full / (ms_full * 1e-3) / 1e12, 2)
+    # ---- N > 1, shard mode: the replica figure BESIDE the sharded one (every GPU bakes its own 8-view group, calls in flight,
+    # no data-path collective): same code as the one-GPU headline, so value(N=1) x N is what perfect weak scaling would read
+    replicas = None
+    if shard is not None and world > 1 and not a.no_replicas_beside and not a.roofline_only:
+        from stable_renderer_amd.pipeline import InflightCalls
+        pipe_r = build_sd15_pipeline(dtype=dtype, n_views=a.views, steps=a.denoise_steps, cfg=8.0, use_graph=not a.no_graph,
+                                     device="cuda:%d" % local, shard=None, controls=controls, **extra)
+        if sdxl:
+            pipe_r.runner.set_vector_conditioning(torch.randn(1, SDXL_CFG["adm_in_channels"], generator=torch.Generator().manual_seed(3)))
+        nfl = 1 if sdxl else max(1, a.inflight)
+        nr = max(nfl, min(a.steps, 2 * nfl))
+        fl = InflightCalls(pipe_r, nfl)
+        fl.warm(1)
+        sync()
+        t1 = time.perf_counter()
+        fl.run(nr)
+        sync()
+        tr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        replicas = {"value": round(a.views * nr * world / max(float(tr.item()), 1e-9), 4), "unit": "frames/s", "scaling": "weak",
+                    "steps": nr, "calls_in_flight_per_gpu": nfl, "parallelism": "view-group replicas x%d" % world}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -244,6 +294,7 @@ def main():
                           "calls_in_flight_per_gpu": inflight, "controlnets": ["depth", "normal"] if a.controlnets else []},
                "exposed_comm_ms_per_denoise_step": None if comm_ms is None else round(comm_ms / max(a.steps * a.denoise_steps, 1), 4),
                "value_1_in_flight": None if one_at_a_time is None else round(one_at_a_time * world, 4),
+               "replicas": replicas,
                "check": check, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist is not None:

@@ -244,8 +244,11 @@ int sr_overlap_csr(const int32_t* ids, const int32_t* pix_cell, int32_t N, int32
  * per latent cell, the mean over all pixels carrying the cell's winning vertexID of the latent they gather (each id pixel counts
  * once; tensor_group_by_then_average, math_utils.py:86-161), blend (1-r)*v + r*mean, then AdaIN(content = x, style = blended)
  * per (n,c) (math_utils.py:55-80).  No floating-point atomics: the segment sum is exact 2^-28 fixed point in int64 and the
- * statistics are fixed-order reductions, so the result is bit-reproducible.  blended: (N,C,lh,lw) fp32, written by the call
- * (the style tensor of the AdaIN; also what tests read). */
+ * statistics are fixed-order reductions, so the result is bit-reproducible.  Range contract of that sum: a finite latent value
+ * saturates at +-4096 (the conversion rounds to nearest 2^-28); a NaN or an infinity in ANY pixel of a vertex makes that
+ * vertex's mean of that channel NaN in every view sharing the vertex -- as the reference's float mean does -- so a diverged
+ * view stays visible to a finiteness check downstream.  blended: (N,C,lh,lw) fp32, written by the call (the style tensor of
+ * the AdaIN; also what tests read). */
 int sr_overlap_step(float* x, const int32_t* cell_vid, const int32_t* vid_off, const int32_t* entries, int32_t N, int32_t C,
                     int32_t lh, int32_t lw, int32_t vid_capacity, float ratio, float* blended, void* stream);
 

@@ -178,44 +178,33 @@ def lib():
     if _lib is None:
         bm = _build_module()
         want = bm.source_hash()
-        have = None
-        if os.path.exists(LIB_PATH):
+        # One builder at a time (ranks of bench --gpus N, spawned test workers and parallel pytest all land here with the same
+        # stale hash): the lock covers the hash check, the compile into csrc/_obj and the rename of the linked file.  The hash
+        # of the file in-tree comes from the sidecar build.py writes, not from dlopen'ing a possibly stale image.
+        import fcntl
+        os.makedirs(os.path.join(_HERE, "csrc", "_obj"), exist_ok=True)
+        with open(os.path.join(_HERE, "csrc", "_obj", ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
             try:
-                have = C.CDLL(LIB_PATH).sr_source_hash
-                have.restype = C.c_char_p
-                have = have().decode()
-            except (OSError, AttributeError):
-                have = None
-        if have != want:
-            if os.environ.get("SR_NO_REBUILD") == "1":
-                raise SrHipError(f"libsr_hip.so is stale or missing (built from {have}, sources are {want}) and SR_NO_REBUILD=1; "
-                                 "there is no CPU fallback for the product path")
-            try:
-                bm.build()
-            except Exception as e:         # no hipcc, compile error: there is no CPU fallback for the product path
-                raise SrHipError(f"libsr_hip.so is stale or missing (built from {have}, sources are {want}) and the rebuild "
-                                 f"failed: {e}\nrun `python stable-renderer_amd/csrc/build.py`; there is no CPU fallback for the "
-                                 "product path") from e
-            if not os.path.exists(LIB_PATH):
-                raise SrHipError(f"{LIB_PATH} not built; there is no CPU fallback for the product path")
-            if have is not None:
-                # the stale image is already mapped into this process (dlopen caches by path): load the new one under a fresh name
-                import shutil
-                import tempfile
-                tmp = os.path.join(tempfile.gettempdir(), f"libsr_hip_{want}_{os.getpid()}.so")
-                shutil.copy2(LIB_PATH, tmp)
-                L = C.CDLL(tmp)
-                for name, (res, args) in SYMBOLS.items():
-                    fn = getattr(L, name)
-                    fn.restype = res
-                    fn.argtypes = args
-                if L.sr_source_hash().decode() != want:
-                    raise SrHipError("rebuilt libsr_hip.so still does not match its sources")
-                _lib = L
-                return _lib
-        L = _load()
+                have = bm.built_hash()
+                if have != want:
+                    if os.environ.get("SR_NO_REBUILD") == "1":
+                        raise SrHipError(f"libsr_hip.so is stale or missing (built from {have}, sources are {want}) and SR_NO_REBUILD=1; "
+                                         "there is no CPU fallback for the product path")
+                    try:
+                        bm.build()
+                    except Exception as e:         # no hipcc, compile error: there is no CPU fallback for the product path
+                        raise SrHipError(f"libsr_hip.so is stale or missing (built from {have}, sources are {want}) and the rebuild "
+                                         f"failed: {e}\nrun `python stable-renderer_amd/csrc/build.py`; there is no CPU fallback for the "
+                                         "product path") from e
+                if not os.path.exists(LIB_PATH):
+                    raise SrHipError(f"{LIB_PATH} not built; there is no CPU fallback for the product path")
+                L = _load()
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
         if L.sr_source_hash().decode() != want:
-            raise SrHipError("libsr_hip.so does not match its sources after the rebuild")
+            raise SrHipError(f"libsr_hip.so (built from {L.sr_source_hash().decode()}) does not match its sources ({want}): "
+                             "remove stable-renderer_amd/csrc/_obj and rebuild")
         _lib = L
     return _lib
 

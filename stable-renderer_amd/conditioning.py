@@ -30,8 +30,24 @@ def entries_of(conditioning):
     return out
 
 
+# keys get_area_and_mult / calc_cond_uncond_batch act on that this package does not implement: an entry carrying one of them
+# is refused instead of being run as if the key were absent (the reference skips such an entry outside its sigma range,
+# samplers.py:62-69, and feeds gligen boxes to the transformer blocks, :103-115)
+_UNSUPPORTED_KEYS = ("timestep_start", "timestep_end", "start_percent", "end_percent", "gligen")
+
+
+def check_supported(entries):
+    for e in entries:
+        bad = [k for k in _UNSUPPORTED_KEYS if e.get(k) is not None and not (k == "start_percent" and float(e[k]) == 0.0)
+               and not (k == "end_percent" and float(e[k]) == 1.0)]
+        if bad:
+            raise NotImplementedError("conditioning entry carries %s (ConditioningSetTimestepRange / GLIGEN): not implemented, "
+                                      "refusing to run it at every step" % ", ".join(bad))
+
+
 def is_plain(entries):
     """one full-area entry with unit strength: the [uncond | cond] fast path applies"""
+    check_supported(entries)
     if len(entries) != 1:
         return False
     e = entries[0]

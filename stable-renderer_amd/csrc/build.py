@@ -71,12 +71,25 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in srcs]
     if jobs or not os.path.exists(LIB):
-        r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        # link under a private name, then rename: a process that dlopens LIB meanwhile sees the old or the new file, never half of one
+        tmp = LIB + ".tmp%d" % os.getpid()
+        r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs, capture_output=True, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        os.replace(tmp, LIB)
     with open(stamp, "w") as f:
         f.write(sh)
     return LIB
+
+
+def built_hash():
+    """source hash the library lying in-tree was built from (the sidecar written after a successful link), or None"""
+    stamp = os.path.join(OBJ, "src.hash")
+    if os.path.exists(LIB) and os.path.exists(stamp):      # (the loader still checks sr_source_hash() of the image it maps)
+        return open(stamp).read().strip()
+    return None
 
 
 if __name__ == "__main__":

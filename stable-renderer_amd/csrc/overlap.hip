@@ -123,11 +123,15 @@ __global__ void overlap_fill(const int4* __restrict__ ids, const int* __restrict
 // ---- per step ---------------------------------------------------------------------------------------------------------------
 // blended[n,c,cell] = (1-r)*x + r*mean over every pixel that carries the cell's winning vertexID (corresponder.py:339-369).
 // Sixteen lanes per latent cell walk the vertex's segment; the sum is taken in 2^-28 fixed point (int64: exact, so neither the
-// segment order nor the lane split can change a bit of the result; |x| is clamped to 4096, 2^21 pixels of one vertex still fit).
+// segment order nor the lane split can change a bit of the result; finite |x| saturates at 4096 -- stated in sr_hip.h -- so 2^21
+// pixels of one vertex still fit).  A NaN or an infinity must not be laundered into a finite mean (the reference's float mean,
+// corresponder.py:339-369, propagates it): every non-finite input raises bit c of `bad`, which travels through the same
+// shuffle reduction and turns the vertex's mean of channel c into NaN.
 constexpr float FIX_SCALE = 268435456.0f;                   // 2^28
-__device__ __forceinline__ long long to_fix(float v) {
+__device__ __forceinline__ long long to_fix(float v, int c, int& bad) {
+  if (!(fabsf(v) <= 3.0e38f)) { bad |= 1 << c; v = 0.f; }   // NaN fails every comparison
   v = fminf(fmaxf(v, -4096.0f), 4096.0f);
-  return (long long)(v * FIX_SCALE);                        // power-of-two scaling is exact; the conversion truncates below 2^-28
+  return __float2ll_rn(v * FIX_SCALE);                      // power-of-two scaling is exact; round to nearest below 2^-28
 }
 constexpr int BLEND_LANES = 16;                            // lanes that share one latent cell's segment walk
 template <int C>
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256) void overlap_blend(const float* __restrict__ x
   const int f = cell / lhw, p = cell - f * lhw;
   long long acc[C];
   for (int c = 0; c < C; ++c) acc[c] = 0;
+  int bad = 0;
   int b = 0, e = 0;
   if (vid >= 0 && vid < cap) { b = off[vid]; e = off[vid + 1]; }
   // two independent entry -> latent chains in flight per lane (the walk is a chain of dependent L2 round trips)
@@ -152,16 +157,17 @@ __global__ __launch_bounds__(256) void overlap_blend(const float* __restrict__ x
     const float* x1 = x + (int64_t)f1 * C * lhw + (c1 - f1 * lhw);
     float v0[C], v1[C];
     for (int c = 0; c < C; ++c) { v0[c] = x0[(int64_t)c * lhw]; v1[c] = x1[(int64_t)c * lhw]; }
-    for (int c = 0; c < C; ++c) acc[c] += to_fix(v0[c]) + to_fix(v1[c]);
+    for (int c = 0; c < C; ++c) acc[c] += to_fix(v0[c], c, bad) + to_fix(v1[c], c, bad);
   }
   if (i < e) {
     const int ce = entries[i];
     const int fe = ce / lhw, pe = ce - fe * lhw;
     const float* xe = x + (int64_t)fe * C * lhw + pe;
-    for (int c = 0; c < C; ++c) acc[c] += to_fix(xe[(int64_t)c * lhw]);
+    for (int c = 0; c < C; ++c) acc[c] += to_fix(xe[(int64_t)c * lhw], c, bad);
   }
   for (int c = 0; c < C; ++c)
     for (int o = 1; o < BLEND_LANES; o <<= 1) acc[c] += __shfl_xor(acc[c], o, BLEND_LANES);
+  for (int o = 1; o < BLEND_LANES; o <<= 1) bad |= __shfl_xor(bad, o, BLEND_LANES);
   if (l < C) {
     long long mine = acc[0];
     for (int c = 1; c < C; ++c) mine = (l == c) ? acc[c] : mine;
@@ -169,7 +175,8 @@ __global__ __launch_bounds__(256) void overlap_blend(const float* __restrict__ x
     const float xv = x[at];
     float out = xv;
     if (e > b) {
-      const float mean = (float)((double)mine / ((double)(e - b) * (double)FIX_SCALE));
+      float mean = (float)((double)mine / ((double)(e - b) * (double)FIX_SCALE));
+      if ((bad >> l) & 1) mean = __builtin_nanf("");
       out = (1.0f - ratio) * xv + ratio * mean;
     }
     blended[at] = out;

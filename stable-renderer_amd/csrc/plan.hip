@@ -32,20 +32,27 @@ static int run_op(const sr_op& op, void* stream) {
 // side lane: one extra stream + two events (fork / join) PER MAIN STREAM (calls in flight on several streams each get their
 // own, created under a mutex on the device that is current when the main stream first forks).  Re-recording an event is
 // safe here: a wait captures the record that precedes it in program order, eagerly and under stream capture alike.
+// The map key is (device, stream handle): a hipStream_t value can come back for a NEW stream once the old one was destroyed,
+// possibly on another device; keyed like this a recycled handle either finds a side stream of its own device (still a valid
+// partner: the lane is nothing but "some other stream of this device" plus two events) or gets a fresh one.
+#include <map>
 #include <mutex>
-#include <unordered_map>
+#include <utility>
 struct sr_side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 static std::mutex g_side_mu;
-static std::unordered_map<void*, sr_side> g_sides;
+static std::map<std::pair<int, void*>, sr_side> g_sides;
 static int side_get(void* main_stream, sr_side* out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "side lane: hipGetDevice");
   std::lock_guard<std::mutex> lk(g_side_mu);
-  auto it = g_sides.find(main_stream);
+  const auto key = std::make_pair(dev, main_stream);
+  auto it = g_sides.find(key);
   if (it == g_sides.end()) {
     sr_side sd;
     if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "side stream");
     if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess)
       SR_FAIL(SR_ERR_LAUNCH, "side events");
-    it = g_sides.emplace(main_stream, sd).first;
+    it = g_sides.emplace(key, sd).first;
   }
   *out = it->second;
   return SR_OK;

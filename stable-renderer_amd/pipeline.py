@@ -182,7 +182,7 @@ class FramePipeline:
         # same views, as the reference's miku-control workflow (depth + normalbae; EngineData.depth_maps / normal_maps ->
         # ControlNetApply)
         self.controls = list(controls or [])
-        self.shard = shard if (shard is not None and shard.world > 1) else None
+        self.shard = shard if (shard is not None and shard.active) else None
         # ControlNets inside a view-sharded group (BASELINE config 4): every rank runs the encoders on its OWN views' hints -- the
         # reference calls the control model without a corresponder (controlnet.py:205-213), so there is no cross-view exchange in it
         self.N_all = n_views
@@ -262,7 +262,7 @@ class FramePipeline:
 
     def diffuse(self, ed, rng_turn=None):
         corr = self.corresponder
-        cb, n_rand = None, None
+        cb, pre, n_rand = None, None, None
         if isinstance(corr, OverlapCorresponder):
             if self.sampler not in ("ddim", "ddpm"):
                 raise ValueError("OverlapCorresponder only works with ddim or ddpm sampler_name.")   # _nodes/samplers.py:163-164
@@ -273,18 +273,27 @@ class FramePipeline:
                     corr.step_finished(ed, ctx)
             else:
                 idx_all = self._ids_all.overlap_index(self.h, self.w)
+                pending = {}
+
+                # the step's input latent is final before its UNet evaluation starts (the evaluation only reads it), so the
+                # all-gather the overlap needs is started HERE and runs on RCCL's stream underneath the evaluation; the
+                # callback after the evaluation only waits for it
+                def pre(x, i, timestep):
+                    if float(timestep) >= corr.step_finished_stop_inject_timestep:
+                        pending[i] = self.shard.gather_latents_start(x)
 
                 def cb(ctx):
                     if ctx.timestep < corr.step_finished_stop_inject_timestep:
                         return
-                    self.shard.overlap_step(ctx.noise, lambda full: idx_all.step(full, corr.step_finished_inject_ratio))
+                    self.shard.overlap_step(ctx.noise, lambda full: idx_all.step(full, corr.step_finished_inject_ratio),
+                                            handle=pending.pop(ctx.step_index, None))
         if self.controls:
             planes = {"depth": lambda: self.normal_depth[..., 3:4].expand(-1, -1, -1, 3), "normal": lambda: self.normal_depth[..., :3],
                       "color": lambda: self.colors, "canny": lambda: self.canny}
             self.runner.set_control_hints([planes[k]().permute(0, 3, 1, 2).float().contiguous() for k, _ in self.controls])
         samples, inj = self.runner.sample(ed.noise_maps["noise"], self.steps, self.sampler, self.scheduler,
                                           latent_image=ed.noise_maps["samples"], inject_n_rand=n_rand, step_callback=cb,
-                                          rng_turn=rng_turn)
+                                          rng_turn=rng_turn, pre_step_callback=pre)
         if isinstance(corr, OverlapCorresponder) and inj is not None:
             corr._random_frame_indices = torch.tensor(inj)
         return samples

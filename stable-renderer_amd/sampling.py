@@ -137,7 +137,7 @@ class DiffusionRunner:
         """shard: optional parallel.ViewShard — this process then holds ``shard.n_local`` of the ``shard.n_views`` views of ONE
         overlapped group; N must equal shard.n_local."""
         self.shard = shard
-        if shard is not None and shard.world > 1:
+        if shard is not None and shard.active:
             assert N == shard.n_local
         self.unet, self.N, self.h, self.w = unet, N, h, w
         # ControlNets (comfy/controlnet.py:180-214 get_control, chained through previous_controlnet: residuals are summed,
@@ -163,7 +163,7 @@ class DiffusionRunner:
     def _ensure_plan(self, inject_idx):
         """the plan depends only on HOW MANY frames are injected; which ones is a device tensor rewritten per run"""
         key = None if inject_idx is None else len(inject_idx)
-        sharded = self.shard is not None and self.shard.world > 1
+        sharded = self.shard is not None and self.shard.active
         if self._plan is None or self._inject != key:
             control, inputs, cn = None, None, None
             if self.controlnets:
@@ -232,10 +232,12 @@ class DiffusionRunner:
         and areas, composed as calc_cond_uncond_batch does (comfy/samplers.py:176-320).  One plain entry each is the ordinary
         [uncond | cond] batch."""
         from . import conditioning as CD
+        CD.check_supported(positive)
+        CD.check_supported(negative)
         if CD.is_plain(positive) and CD.is_plain(negative):
             self._entries = None
             return self.set_conditioning(positive[0]["cond"], negative[0]["cond"])
-        if self.shard is not None and self.shard.world > 1:
+        if self.shard is not None and self.shard.active:
             raise NotImplementedError("mask / area conditioning lists inside a view-sharded group")
         self._entries = (list(positive), list(negative))
         self._general = None
@@ -247,10 +249,6 @@ class DiffusionRunner:
         C = self.unet.cfg["in_channels"]
         pos, neg = CD.prepare(self._entries[0], self._entries[1], h, w)
         groups = CD.groups_of(pos, neg, N, C, h, w, use_uncond=self.copies == 2)
-        if n_rand is not None and len(groups) != 1:
-            raise NotImplementedError("K/V injection (OverlapCorresponder) with conditioning areas that need several model calls")
-        if self.controlnets and any(g["area"] != (h, w, 0, 0) for g in groups):
-            raise NotImplementedError("ControlNets with conditioning areas (the hint would need the same crop)")
         dev = self.x.device
         for g in groups:
             ah, aw, _, _ = g["area"]
@@ -263,6 +261,15 @@ class DiffusionRunner:
                              out_c=torch.empty_like(self.x), cnt_c=torch.empty_like(self.x),
                              out_u=torch.empty_like(self.x), cnt_u=torch.empty_like(self.x))
         return self._general
+
+    def _check_general(self, n_rand):
+        """the combinations the general path does not run -- checked on EVERY sample() call, not only when the group list is
+        first built (a later call may add K/V injection or ControlNets to a cached list)"""
+        groups = self._general["groups"]
+        if n_rand is not None and len(groups) != 1:
+            raise NotImplementedError("K/V injection (OverlapCorresponder) with conditioning areas that need several model calls")
+        if self.controlnets and any(g["area"] != (self.h, self.w, 0, 0) for g in groups):
+            raise NotImplementedError("ControlNets with conditioning areas (the hint would need the same crop)")
 
     def _general_plans(self, inject):
         """build (once per injected-frame COUNT) and load the plans of the general path"""
@@ -408,31 +415,40 @@ class DiffusionRunner:
                             src[j].copy_(ln[li])
                         pending.append(PAR.broadcast_start(src[j], owner, self.shard.group))
             else:                                            # "wait"
-                if self.time_comm:
+                # only a transfer that really runs beside the compute stream (RCCL) has an exposed part to time; the staged
+                # gloo form completed inside broadcast_start, two events around a no-op would measure nothing
+                timed = self.time_comm and any(h.is_async for h in pending)
+                if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                 for h in pending:
                     h.wait()
-                if self.time_comm:
+                if timed:
                     e1.record()
                     self._comm_events.append((e0, e1))
                 pending = []
         return p["out"]
 
     def exposed_comm_ms(self):
-        """sum of the compute-stream stalls recorded since the last call (needs time_comm = True); synchronises"""
+        """sum of the compute-stream stalls in the K/V-source waits recorded since the last call (needs time_comm = True);
+        None when no asynchronous transfer was waited for (gloo staging, one rank); synchronises"""
         torch.cuda.synchronize()
+        if not self._comm_events:
+            return None
         ms = sum(a.elapsed_time(b) for a, b in self._comm_events)
         self._comm_events = []
         return ms
 
     def sample(self, noise, steps, sampler_name, scheduler, denoise=1.0, latent_image=None, seed=None,
-               inject_n_rand=None, step_callback=None, noise_fn=None, rng_turn=None):
+               inject_n_rand=None, step_callback=None, noise_fn=None, rng_turn=None, pre_step_callback=None):
         """-> samples (N,4,h,w) fp32 on device (already divided by the latent scale, samplers.py:933).
 
         RNG draw order on the *global CPU generator* replicates the reference: custom_ksampler's seed draw
         (nodes.py:1455), SAMPLER_METHOD's reseed+draw for "ddim" (samplers.py:766-768), pre_atten_inject's randint
-        on the first attention block (corresponder.py:204-205), then the sampler's per-step randn_like."""
+        on the first attention block (corresponder.py:204-205), then the sampler's per-step randn_like.
+
+        pre_step_callback(x, i, timestep): called before the model evaluation of step i with the step's input latent (the
+        evaluation only reads it) -- the view-sharded pipeline starts the latent all-gather of the step's overlap here."""
         ks = KSampler(steps, sampler_name, scheduler, denoise, self.ms)
         sig = ks.sigmas
         sampler = ks.sampler_name
@@ -450,14 +466,15 @@ class DiffusionRunner:
             general = getattr(self, "_entries", None) is not None
             G = None
             if general:
-                G = self._general if self._general is not None else self._build_general(
-                    inject_n_rand if (inject_n_rand is not None and inject_n_rand >= 0) else None)
+                n_rand_ = inject_n_rand if (inject_n_rand is not None and inject_n_rand >= 0) else None
+                G = self._general if self._general is not None else self._build_general(n_rand_)
+                self._check_general(n_rand_)
             inject = None
             if inject_n_rand is not None and inject_n_rand >= 0:
                 n_all = self.N if self.shard is None else self.shard.n_views
                 B = n_all * (G["groups"][0]["chunks"] if general else self.copies)
                 inject = torch.randint(1, B, (inject_n_rand,)).tolist()       # global RNG; B counts cond + uncond entries
-                if self.shard is not None and self.shard.world > 1:           # every rank must use rank 0's draw
+                if self.shard is not None and self.shard.active:              # every rank must use rank 0's draw
                     from . import parallel as PAR
                     t_inj = torch.tensor(inject, dtype=torch.int64)
                     PAR.broadcast(t_inj, 0, self.shard.group)
@@ -481,6 +498,8 @@ class DiffusionRunner:
         t_index = [int(t) for t in self.ms.timestep(sig[:-1])]          # ModelSamplingDiscrete.timestep, once per run
         for i in range(len(sig) - 1):
             s, sn = float(sig[i]), float(sig[i + 1])
+            if pre_step_callback is not None:
+                pre_step_callback(self.x, i, ks.timesteps[i])
             if general:
                 self._general_denoise(s, t_index[i], sampler in ("euler", "ddim"))
             else:
@@ -499,7 +518,10 @@ class DiffusionRunner:
         out = torch.empty_like(self.x)
         out.zero_()
         O.axpby(out, self.x, 1.0 / self.latent_scale, 0.0)
-        if p.get("inject_err") is not None and int(p["inject_err"].item()) != 0:      # the run's one host sync (results are due anyway)
-            p["inject_err"].zero_()
+        run_plans = [g["plan"] for g in G["groups"]] if general else [p]
+        flags = [q["inject_err"] for q in run_plans if q.get("inject_err") is not None]
+        if flags and int(torch.stack([f.reshape(()) for f in flags]).max().item()) != 0:      # the run's one host sync (results are due anyway)
+            for f in flags:
+                f.zero_()
             raise IndexError("injected frame index outside the batch reached sr_gather_rows (k_context[idx], corresponder.py:207-214)")
         return out, inject

@@ -476,6 +476,33 @@ def test_idmap_and_overlap_index_on_reference_sphere_ids(ops):
         assert np.array_equal(s_exp, s_got)
 
 
+def test_overlap_step_propagates_non_finite_latents(ops):
+    """a NaN / infinity in one view must reach the mean of every view sharing the vertex (the reference's float mean does,
+    corresponder.py:339-369) instead of being clamped into a finite value by the fixed-point sum"""
+    d = np.load(os.path.join(GOLD, "overlap_step.npz"))
+    meta = json.loads(bytes(d["meta"]).decode())
+    name = next(n for n, m in meta.items() if m["timestep"] >= m["stop"] and d[f"{n}_x"].shape[0] >= 2)
+    ids = torch.from_numpy(d[f"{name}_ids"]).cuda()
+    x = torch.from_numpy(d[f"{name}_x"]).clone()
+    idx = ops.OverlapIndex(ids, x.shape[2], x.shape[3])
+    off, ent, cv = idx.vid_off.cpu().numpy(), idx.entries.cpu().numpy(), idx.cell_vid.cpu().numpy()
+    lhw = x.shape[2] * x.shape[3]
+    # a vertex seen from two different views whose cells both have it as their winning vertex
+    v = next(v for v in range(idx.cap) if off[v + 1] - off[v] >= 2 and len({c // lhw for c in ent[off[v]:off[v + 1]]}) >= 2
+             and sum(cv[c] == v for c in set(ent[off[v]:off[v + 1]])) >= 2)
+    cells = sorted({int(c) for c in ent[off[v]:off[v + 1]] if cv[c] == v})
+    src = cells[0]
+    for bad in (float("nan"), float("inf")):
+        xb = x.clone()
+        xb.view(x.shape[0], x.shape[1], lhw)[src // lhw, 1, src % lhw] = bad
+        bl = torch.empty_like(xb).cuda()
+        idx.step(xb.cuda(), meta[name]["ratio"], blended_out=bl)
+        b = bl.cpu().view(x.shape[0], x.shape[1], lhw)
+        for c in cells:                                      # channel 1 of every cell of that vertex, in every view
+            assert not np.isfinite(float(b[c // lhw, 1, c % lhw]))
+            assert np.isfinite(float(b[c // lhw, 0, c % lhw]))   # other channels untouched
+
+
 def test_overlap_nonsquare_raises(ops):
     ids = torch.ones(1, 48, 32, 4, dtype=torch.int32).cuda()
     with pytest.raises(IndexError):

@@ -14,14 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _guarded(body, rank, world, port, q):
+def _guarded(body, rank, world, port, q, backend="gloo"):
     """worker shell: any failure travels to the parent as ('error', traceback) instead of leaving it blocked on the queue"""
     import traceback
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     try:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":                               # RCCL: a fresh process, the group is made before any other GPU work
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         try:
             q.put((rank, "ok", body(rank, world)))
         finally:
@@ -211,3 +214,52 @@ def test_two_ranks_three_frames_each_with_two_controlnets_match_single_process()
         assert moved > 1e-3, moved
         if rank == 0:
             assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ["SR_SHARD_FORCE"] = "1"                      # keep every collective of the sharded path in a one-rank group
+    _guarded(_rccl_body, rank, world, port, q, backend="nccl")
+
+
+def _rccl_body(rank, world):
+    """The sharded code path over the REAL backend: a world-size-1 `nccl` (= RCCL) group on the one GPU of the box, with the
+    one-rank early-outs disabled (SR_SHARD_FORCE).  What executes through RCCL: the random-frame broadcast, the id-map
+    all-gather, per denoise step the ASYNCHRONOUS latent all-gather (started before the UNet evaluation, waited for in the step
+    callback), per transformer block dist.broadcast(async_op=True) + Work.wait() between the cut plan segments (eager and as
+    hipGraphs), and the frame gather to rank 0.  The result must equal the plain single-process pipeline."""
+    from stable_renderer_amd.pipeline import build_sd15_pipeline
+    from stable_renderer_amd.parallel import ViewShard
+    from stable_renderer_amd.unet import SD15_CFG
+    torch.cuda.set_device(0)
+    assert dist.get_backend() == "nccl"
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    kw = dict(dtype=torch.float32, n_views=4, steps=3, cfg=5.0, W=128, H=128, unet_cfg=cfg, vae_ch=32)
+
+    def run(shard, graph):
+        pipe = build_sd15_pipeline(shard=shard, use_graph=graph, **kw)
+        pipe.runner.time_comm = shard is not None
+        torch.manual_seed(7)
+        imgs = pipe.call().clone()
+        torch.cuda.synchronize()
+        return pipe, imgs
+    os.environ["SR_SHARD_FORCE"] = "0"
+    p0, base = run(None, False)
+    os.environ["SR_SHARD_FORCE"] = "1"
+    sh = ViewShard(4)
+    assert sh.active and sh.world == 1 and sh.n_local == 4
+    p1, eager = run(sh, False)
+    assert p1.shard is sh and p1.runner._plan["schedule"], "the sharded schedule was not used"
+    comm_eager = p1.runner.exposed_comm_ms()
+    p2, graph = run(sh, True)
+    comm_graph = p2.runner.exposed_comm_ms()
+    c0, c1 = p0.scene.corrmap, p2.scene.corrmap
+    same = (bool((c0._writtens == c1._writtens).all()), int(c0._writtens.sum()), (c0._values - c1._values).abs().max().item())
+    return ((eager - base).abs().max().item(), (graph - eager).abs().max().item(), comm_eager, comm_graph, same)
+
+
+def test_sharded_path_runs_through_rccl_in_a_one_rank_group():
+    (err, err_g, comm_e, comm_g, same), = _run_ranks(_rccl_worker, 1, 26700 + (os.getpid() % 1000), timeout=600)
+    assert err < 2e-4, err
+    assert err_g < 1e-5, err_g
+    assert comm_e is not None and comm_g is not None and comm_e >= 0.0 and comm_g >= 0.0      # asynchronous waits were timed
+    assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same

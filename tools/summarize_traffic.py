@@ -5,7 +5,9 @@ step plan = 12 evaluations' worth of igemm launches (the few extra launches of t
 K/V and time-embedding GEMMs, run once per sampling run — are counted in: < 0.5 % of the bytes)."""
 import csv
 import glob
+import importlib.util
 import json
+import os
 import sys
 
 out = sys.argv[1]
@@ -32,4 +34,11 @@ res = {"fetch_size_kb_sum": fetch_kb, "write_size_kb_sum": write_kb, "dispatches
        "note": "FETCH_SIZE x2 (gfx950 counts 16-B-per-lane reads at half); igemm family = igemm_kernel tiles + conv3p_kernel + splitk_reduce_kernel"}
 if evals:
     res["hbm_bytes_per_eval"] = res["fetch_bytes_per_eval_corrected"] + res["write_bytes_per_eval"]
+# identity of the kernels that were counted: bench.py quotes the figure only while the loaded library has this source hash
+_bp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stable-renderer_amd", "csrc", "build.py")
+_spec = importlib.util.spec_from_file_location("sr_build", _bp)
+_bm = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_bm)
+res["source_hash"] = _bm.source_hash()
+res["workload"] = "bench.py --roofline-only (sd15-512, 8 views, f16, B=16 UNet evaluation)"
 print(json.dumps(res, indent=1))
