@@ -82,6 +82,7 @@ def test_stale_library_is_refused(monkeypatch, tmp_path):
     monkeypatch.setenv("SR_NO_REBUILD", "1")
     real = bm.source_hash()
     monkeypatch.setattr(_lib, "_build_module", lambda: type("B", (), {"source_hash": staticmethod(lambda: "deadbeef" + real[8:]),
+                                                                      "built_hash": staticmethod(bm.built_hash),
                                                                       "build": staticmethod(lambda: None)}))
     with pytest.raises(_lib.SrHipError, match="stale or missing"):
         _lib.lib()
