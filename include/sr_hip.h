@@ -83,10 +83,18 @@ typedef struct {
                              offsets; SR_ERR_INVALID otherwise), 9 = 128x160 and 10 = 128x320 with 64-byte K-steps (fp16; two co-resident
                              workgroups per CU for the K-short linear layers), 11 = 128x128 as 8 waves and 12 = 256x128 with 64-byte K-steps
                              (fp16; the same for widths that are multiples of 128 only).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
-  int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split                      */
+  int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split, 2..16 = split the
+                             partly empty last round of workgroups this many ways over K (tiles 2 / 3; what the
+                             per-shape tuner measures)                                                          */
   int32_t pad_br;         /* 1: a 3x3 conv pads ONLY the bottom / right border (window of output (y,x) starts at input
                              (y*stride, x*stride)): the VAE encoder's Downsample = F.pad(x, (0,1,0,1)) + conv(stride 2,
                              padding 0) (comfy/ldm/modules/diffusionmodules/model.py:77-95).  0: symmetric KH/2 padding          */
+  const void* prefetch;   /* optional: bytes another launch will stream soon (the packed weights of the NEXT igemm of a plan).  Every
+                             workgroup touches its share of them at kernel start (one 4-byte LDS-DMA read per 64 bytes, the data
+                             is discarded), so they sit in the Infinity Cache when their layer starts instead of coming from HBM
+                             on that layer's critical path (a UNet evaluation streams 1.7 GB of weights, far more than the
+                             256 MB cache keeps between evaluations).  NULL = none.  Never changes a result.                    */
+  int64_t prefetch_bytes;
   int32_t up_h, up_w;     /* with upsample = 1: output size of the fused nearest upsample when it is not exactly 2H x 2W (0 = x2);
                              src = floor(dst * in/out) as F.interpolate(mode="nearest"): odd-sized latents (conditioning areas)
                              where Upsample.forward targets the skip tensor's size (openaimodel.py:109-121)                      */

@@ -1,0 +1,331 @@
+"""TEST INFRASTRUCTURE (container only): golden vectors AT THE BASELINE SHAPES, made by running the *reference's own stack*
+(custom_ksampler -> comfy.sample -> KSampler -> calc_cond_uncond_batch -> BaseModel.apply_model -> UNetModel, the reference
+OverlapCorresponder / ControlNet wrapper / VAE Decoder) on CPU, imported from /root/reference through oracle/_ref_import.py.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_full.py [section ...]
+
+Why fixtures instead of running the oracle beside the GPU run: a B = 16 evaluation of the 860 M-parameter UNet costs the host
+minutes, so the full-size cases (8 views, ControlNets at real width, the 2.57 B-parameter SDXL UNet) would not fit the GPU
+suite; run here once, they cost the suite nothing -- and they are the reference's outputs, not a restatement's.
+
+Inputs are the G-buffers of this repo's scenes rasterised by oracle/raster_ref.c (the C statement of the shaders the HIP
+rasteriser reproduces bit for bit: tests/test_gpu_raster.py) and pooled by the oracle's _save_frame_data restatement; a fixture
+stores the latent noise it was made from, a SHA-256 of the id maps (the GPU test re-rasterises with the HIP kernel and must hit
+the same bytes), the seeds, the reference's samples and a 4x-subsampled fp16 copy of its decoded frames.  Weights are seeded
+(synth.fill_module_ on the reference modules == synth.synth_state_dict on this package's name tables; asserted below).
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import _ref_import as R  # noqa: E402
+
+_ARGV = sys.argv[1:]
+R.install()
+import gen_golden as GG  # noqa: E402  (configs, quiet / one_thread guards, save)
+import raster_ref as RR  # noqa: E402
+import sr_oracle as ORC  # noqa: E402
+from stable_renderer_amd import scene as S  # noqa: E402
+from stable_renderer_amd import synth  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def raster_views(scene, n_views, frame0=0, bg_seed=1):
+    """what FramePipeline.render_views produces, on the CPU: C-oracle G-buffers -> (ids, latent noise, normal+depth planes)"""
+    W, H = scene.W, scene.H
+    ref = RR.GBufferRef(W, H)
+    view, proj = scene.camera.view(), scene.camera.projection(W / H)
+    bg = torch.randn(1, H, W, 4, generator=torch.Generator().manual_seed(bg_seed))
+    ids, noise, nd = [], [], []
+    for i in range(n_views):
+        ref.clear()
+        for t in sorted(scene.tasks(frame0 + i), key=lambda t: t.order):
+            ref.draw(t, S.draw_params(t, view, proj),
+                     noise_tex=None if t.noise_tex is None else t.noise_tex.cpu().numpy().view(np.uint16),
+                     diffuse_tex=None if t.diffuse_tex is None else t.diffuse_tex.cpu().numpy())
+        ids.append(ref.id.copy())
+        color = torch.from_numpy(ref.color.copy().view(np.float16))
+        npl = torch.from_numpy(ref.noise.copy().view(np.float16))
+        _, nz = ORC.noise_pool(npl.unsqueeze(0), color[..., 3].contiguous().unsqueeze(0), bg)
+        noise.append(nz[0])
+        nd.append(ref.normal_depth.copy())
+    return np.stack(ids), torch.stack(noise).contiguous(), np.stack(nd)
+
+
+def check_names(ns, ours):
+    assert [(n, tuple(s)) for n, s in ns] == [(n, tuple(s)) for n, s in ours], "name table differs from the reference state_dict"
+
+
+def ref_model(unet_config, seed, family="sd15"):
+    import comfy.model_base
+    import comfy.model_patcher
+    import comfy.supported_models
+    cls = comfy.supported_models.SDXL if family == "sdxl" else comfy.supported_models.SD15
+    mc = cls(dict(unet_config))
+    mc.unet_config = dict(unet_config)
+    mc.set_inference_dtype(torch.float32, None)
+    mb = comfy.model_base.SDXL if family == "sdxl" else comfy.model_base.BaseModel
+    bm = mb(mc, model_type=comfy.model_base.ModelType.EPS, device="cpu")
+    bm.eval()
+    ns, norm = synth.fill_module_(bm.diffusion_model, seed=seed)
+    mp = comfy.model_patcher.ModelPatcher(bm, load_device=torch.device("cpu"), offload_device=torch.device("cpu"))
+    return mp, ns, norm
+
+
+def ref_sample(mp, noise, pos, neg, ids, steps, cfg, sampler, sched, rng_seed, overlap=None):
+    """CorrespondSampler's call (_nodes/samplers.py:187-201): zero latent + incoming engine noise, seed drawn from the global
+    RNG; with an OverlapCorresponder its step_finished is the step callback and it rides along as `corresponder`"""
+    import common_utils.stable_render_utils.corresponder as co
+    import nodes as ref_nodes
+    cm = R.import_corrmap()
+
+    class ED:
+        pass
+    ed = ED()
+    kwargs, callbacks, oc = {}, [], None
+    if ids is not None:
+        with GG.quiet():
+            ed.id_maps = cm.IDMap(tensor=torch.from_numpy(ids).clone())
+    if overlap is not None:
+        oc = co.OverlapCorresponder(step_finished_inject_ratio=overlap["ratio"], step_finished_stop_inject_timestep=overlap["stop"],
+                                    pre_attn_inject_num_random_frames=overlap.get("n_rand", 1))
+
+        def on_step(engine_data, context):
+            with GG.one_thread():
+                oc.step_finished(engine_data, context)
+        callbacks = [partial(on_step, ed)]
+        kwargs = dict(engine_data=ed, corresponder=oc)
+    torch.manual_seed(rng_seed)
+    N, _, h, w = noise.shape
+    latent = {"samples": torch.zeros(N, 4, h, w), "noise": noise.clone()}
+    with GG.quiet(), torch.no_grad():
+        s = ref_nodes.custom_ksampler(model=mp, seed=None, steps=steps, cfg=cfg, sampler_name=sampler, scheduler=sched,
+                                      positive=pos, negative=neg, latent=latent, denoise=1.0, noise_option='incoming',
+                                      callbacks=list(callbacks), **kwargs)[0]["samples"]
+    inj = None if oc is None or oc._random_frame_indices is None else [int(i) for i in oc._random_frame_indices]
+    return s, inj
+
+
+_DEC = {}
+
+
+def ref_decode(samples, seed=2):
+    """VAE.decode's arithmetic (comfy/sd.py:329-346) with the reference Decoder -> (N,H,W,3) in [0,1]"""
+    from comfy.ldm.modules.diffusionmodules.model import Decoder
+    import comfy.ops  # noqa: F401
+    if seed not in _DEC:
+        dd = {'double_z': True, 'z_channels': 4, 'resolution': 256, 'in_channels': 3, 'out_ch': 3, 'ch': 128,
+              'ch_mult': [1, 2, 4, 4], 'num_res_blocks': 2, 'attn_resolutions': [], 'dropout': 0.0}
+        d = Decoder(**dd)
+        d.eval()
+        synth.fill_module_(d, seed=seed)
+        _DEC[seed] = d
+    outs = []
+    with torch.no_grad():
+        for i in range(samples.shape[0]):
+            y = _DEC[seed](samples[i:i + 1])
+            outs.append(torch.clamp((y + 1.0) / 2.0, min=0.0, max=1.0).movedim(1, -1))
+    return torch.cat(outs, 0)
+
+
+def sub4(img):
+    return img[:, ::4, ::4].to(torch.float16)
+
+
+def ctx(seed, dim=768):
+    return torch.randn(1, 77, dim, generator=torch.Generator().manual_seed(seed))
+
+
+def attention_basic():
+    import comfy.ldm.modules.attention as att
+    att.optimized_attention = att.attention_basic
+
+
+def _sd15_names():
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    from stable_renderer_amd.unet import SD15_CFG
+    return unet_names_shapes(SD15_CFG)[0]
+
+
+# ---- the bench workload's shape: 8 overlapped views, 512^2, full SD1.5 UNet + VAE -------------------
+def sec_bench8():
+    from stable_renderer_amd.pipeline import BakeBallScene
+    attention_basic()
+    t0 = time.time()
+    ids, noise, _ = raster_views(BakeBallScene(512, 512, k=6, device="cpu"), 8)
+    mp, ns, _ = ref_model(GG.SD15, 0)
+    check_names(ns, _sd15_names())
+    pos, neg = [[ctx(1), {}]], [[ctx(2), {}]]
+    s, inj = ref_sample(mp, noise, pos, neg, ids, 3, 8.0, "ddim", "normal", 1234, overlap=dict(ratio=0.5, stop=500, n_rand=1))
+    print("bench8: sampling %.0f s" % (time.time() - t0))
+    img = ref_decode(s)
+    GG.save("full_bench8", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, img_sub=sub4(img),
+            inj=np.array(inj), meta=np.frombuffer(json.dumps(dict(views=8, steps=3, sampler="ddim", scheduler="normal", cfg=8.0,
+                                                                 rng_seed=1234, pos_seed=1, neg_seed=2, unet_seed=0, vae_seed=2,
+                                                                 ratio=0.5, stop=500)).encode(), np.uint8))
+    print("bench8: %.0f s" % (time.time() - t0))
+
+
+# ---- BASELINE config 2: bake_ball, 1 view, 20 steps (was: oracle run beside the GPU run, 84 s of the GPU suite) ----------
+def sec_config2():
+    from stable_renderer_amd.pipeline import BakeBallScene
+    attention_basic()
+    t0 = time.time()
+    ids, noise, _ = raster_views(BakeBallScene(512, 512, k=6, device="cpu"), 1)
+    mp, ns, _ = ref_model(GG.SD15, 0)
+    s, _ = ref_sample(mp, noise, [[ctx(1), {}]], [[ctx(2), {}]], None, 20, 8.0, "euler", "normal", 7)
+    img = ref_decode(s)
+    GG.save("full_config2", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, img_sub=sub4(img),
+            meta=np.frombuffer(json.dumps(dict(views=1, steps=20, sampler="euler", scheduler="normal", cfg=8.0, rng_seed=7,
+                                               pos_seed=1, neg_seed=2, unet_seed=0, vae_seed=2)).encode(), np.uint8))
+    print("config2: %.0f s" % (time.time() - t0))
+
+
+# ---- BASELINE config 3: mesh through Mesh.Load, 2 overlapped views, 20 steps ------------------------------------------------
+def sec_config3():
+    from stable_renderer_amd.pipeline import BoatScene
+    attention_basic()
+    t0 = time.time()
+    ids, noise, _ = raster_views(BoatScene(os.path.join(GOLD, "boatlike.obj"), 512, 512, k=6, device="cpu"), 2)
+    mp, ns, _ = ref_model(GG.SD15, 0)
+    s, inj = ref_sample(mp, noise, [[ctx(3), {}]], [[ctx(4), {}]], ids, 20, 8.0, "ddim", "normal", 11,
+                        overlap=dict(ratio=0.5, stop=500, n_rand=1))
+    img = ref_decode(s)
+    GG.save("full_config3", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, img_sub=sub4(img), inj=np.array(inj),
+            meta=np.frombuffer(json.dumps(dict(views=2, steps=20, sampler="ddim", scheduler="normal", cfg=8.0, rng_seed=11,
+                                               pos_seed=3, neg_seed=4, unet_seed=0, vae_seed=2, ratio=0.5, stop=500)).encode(), np.uint8))
+    print("config3: %.0f s" % (time.time() - t0))
+
+
+# ---- BASELINE config 4 at real width: SD1.5 UNet + two full-width ControlNets driven by the G-buffers -----------------------
+def sec_config4():
+    import comfy.cldm.cldm as cldm
+    import comfy.controlnet
+    import comfy.ops
+    import nodes as ref_nodes
+    from stable_renderer_amd.model_shapes import controlnet_names_shapes
+    from stable_renderer_amd.pipeline import BakeBallScene
+    from stable_renderer_amd.unet import SD15_CFG
+    attention_basic()
+    t0 = time.time()
+    ids, noise, nd = raster_views(BakeBallScene(512, 512, k=6, device="cpu"), 2)
+    ndf = torch.from_numpy(nd.view(np.float16)).float()                          # (N,H,W,4): rgb = normal, a = depth
+    hints = {"depth": ndf[..., 3:4].expand(-1, -1, -1, 3).contiguous(), "normal": ndf[..., :3].contiguous()}
+    mp, ns, _ = ref_model(GG.SD15, 0)
+    cfg = {k: v for k, v in GG.SD15.items() if k not in ("out_channels", "transformer_depth_output")}
+    pos, neg = [[ctx(5), {}]], [[ctx(6), {}]]
+    for i, (plane, strength) in enumerate((("depth", 1.0), ("normal", 0.7))):
+        cn = cldm.ControlNet(hint_channels=3, operations=comfy.ops.disable_weight_init, **cfg)
+        cn.eval()
+        cns, _ = synth.fill_module_(cn, seed=20 + i)
+        check_names(cns, controlnet_names_shapes(SD15_CFG)[0])
+        wrapped = comfy.controlnet.ControlNet(cn, load_device=torch.device("cpu"))
+        pos = ref_nodes.ControlNetApply().apply_controlnet(pos, wrapped, hints[plane], strength)[0]
+    s, _ = ref_sample(mp, noise, pos, neg, None, 3, 8.0, "euler", "normal", 21)
+    # the same run without the ControlNets: the test also checks that the nets move the result
+    s_plain, _ = ref_sample(mp, noise, [[ctx(5), {}]], [[ctx(6), {}]], None, 3, 8.0, "euler", "normal", 21)
+    img = ref_decode(s)
+    GG.save("full_config4", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), nd_sha=np.frombuffer(sha(nd).encode(), np.uint8),
+            samples=s, samples_plain=s_plain, img_sub=sub4(img),
+            meta=np.frombuffer(json.dumps(dict(views=2, steps=3, sampler="euler", scheduler="normal", cfg=8.0, rng_seed=21, pos_seed=5,
+                                               neg_seed=6, unet_seed=0, vae_seed=2, cn_seeds=[20, 21], planes=["depth", "normal"],
+                                               strengths=[1.0, 0.7])).encode(), np.uint8))
+    print("config4: %.0f s" % (time.time() - t0))
+
+
+# ---- BASELINE config 5 ---------------------------------------------------------------------------------------------------------
+SDXL_FULL = {'use_checkpoint': False, 'image_size': 32, 'out_channels': 4, 'use_spatial_transformer': True, 'legacy': False,
+             'num_classes': 'sequential', 'adm_in_channels': 2816, 'dtype': torch.float32, 'in_channels': 4, 'model_channels': 320,
+             'num_res_blocks': [2, 2, 2], 'transformer_depth': [0, 0, 2, 2, 10, 10], 'channel_mult': [1, 2, 4],
+             'transformer_depth_middle': 10, 'use_linear_in_transformer': True, 'context_dim': 2048, 'num_head_channels': 64,
+             'num_heads': -1, 'transformer_depth_output': [0, 0, 0, 2, 2, 2, 10, 10, 10],
+             'use_temporal_attention': False, 'use_temporal_resblock': False}      # comfy/supported_models.py:153-160
+
+
+def sec_sdxl_full():
+    """ONE forward of the full-width SDXL base UNet (2.57 B parameters: 64-wide heads, depth-10 transformers, linear projections,
+    label_emb) through the reference UNetModel: B = 2, 32x32 latent"""
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    from stable_renderer_amd.unet import SDXL_CFG
+    attention_basic()
+    t0 = time.time()
+    with torch.no_grad():
+        m, ns, norm = GG.build_unet(SDXL_FULL, seed=8)
+        check_names(ns, unet_names_shapes(SDXL_CFG)[0])
+        x = GG.rnd(21, 2, 4, 32, 32)
+        t = torch.tensor([601.0, 601.0])
+        c = GG.rnd(22, 2, 77, 2048)
+        yv = GG.rnd(23, 2, 2816)
+        y = m(x, t, context=c, y=yv, transformer_options={})
+    GG.save("unet_sdxl_full_32", x=x, t=t, ctx=c, yvec=yv, y=y, seed=np.array(8))
+    print("sdxl_full: %.0f s" % (time.time() - t0))
+
+
+SDXL_TINY2 = dict(GG.SDXL_TINY, adm_in_channels=2816)       # the width SDXL.encode_adm produces (pooled 1280 + 6 x 256)
+
+
+def sec_config5():
+    """the multi-object scene through the reference's SDXL model class (model_base.SDXL: encode_adm -> y -> label_emb) at 1/5
+    width with OverlapCorresponder: 3 views, 256^2, ddim"""
+    from stable_renderer_amd.pipeline import MultiObjScene
+    attention_basic()
+    t0 = time.time()
+    ids, noise, _ = raster_views(MultiObjScene(os.path.join(GOLD, "boatlike.obj"), 256, 256, k=6, device="cpu"), 3)
+    mp, ns, norm = ref_model(SDXL_TINY2, 9, family="sdxl")
+    GG._jdump({"names_shapes": ns, "norm_names": norm}, os.path.join(GOLD, "unet_sdxl_tiny2_keys.json"))
+    pp, pn = GG.rnd(31, 1, 1280), GG.rnd(32, 1, 1280)
+    pos, neg = [[ctx(33, 128), {"pooled_output": pp}]], [[ctx(34, 128), {"pooled_output": pn}]]
+    s, inj = ref_sample(mp, noise, pos, neg, ids, 3, 6.0, "ddim", "normal", 55, overlap=dict(ratio=0.5, stop=500, n_rand=1))
+    GG.save("full_config5", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, inj=np.array(inj),
+            pooled_pos=pp, pooled_neg=pn,
+            meta=np.frombuffer(json.dumps(dict(views=3, steps=3, sampler="ddim", scheduler="normal", cfg=6.0, rng_seed=55, pos_seed=33,
+                                               neg_seed=34, unet_seed=9, ratio=0.5, stop=500, size=256)).encode(), np.uint8))
+    print("config5: %.0f s" % (time.time() - t0))
+
+
+# ---- pre_atten_inject with TWO random frames (K/V length 2 x hw, corresponder.py:204-220) --------------------------------------
+def sec_nrand2():
+    import common_utils.stable_render_utils.corresponder as co
+    attention_basic()
+    with torch.no_grad():
+        m, ns, norm = GG.build_unet(GG.TINY, seed=1)
+        x = GG.rnd(1, 4, 4, 16, 16)
+        t = torch.tensor([981.0, 981.0, 981.0, 981.0])
+        c = GG.rnd(2, 4, 77, 64)
+        oc = co.OverlapCorresponder(pre_attn_inject_num_random_frames=2)
+        oc._random_frame_indices = torch.tensor([3, 1])
+        y2 = m(x, t, context=c, transformer_options={"positive_cond_indices": [2, 3]}, engine_data=object(), corresponder=oc)
+    mp, _, _ = ref_model(GG.TINY, 1)
+    N, H, W = 3, 128, 128
+    ids = GG.synth_ids(300, N, H, W, n_vertex=500)
+    noise = GG.rnd(13, N, 4, H // 8, W // 8)
+    pos, neg = [[GG.rnd(11, 1, 77, 64), {}]], [[GG.rnd(12, 1, 77, 64), {}]]
+    s, inj = ref_sample(mp, noise, pos, neg, ids.numpy() if isinstance(ids, torch.Tensor) else ids, 4, 7.5, "ddim", "normal", 4242,
+                        overlap=dict(ratio=0.5, stop=500, n_rand=2))
+    GG.save("inject2_tiny", x=x, t=t, ctx=c, y_inj2=y2, inj_idx=np.array([3, 1]), ids=ids, noise=noise, pos=pos[0][0], neg=neg[0][0],
+            samples=s, e2e_inj=np.array(inj), rng_seed=np.array(4242))
+
+
+SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, config4=sec_config4, bench8=sec_bench8,
+                config2=sec_config2, config3=sec_config3)
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    for s_ in (_ARGV or list(SECTIONS)):
+        print("==", s_, flush=True)
+        SECTIONS[s_]()

@@ -22,7 +22,8 @@ class IgemmArgs(C.Structure):
                 ("zero_page", vp), ("B", i32), ("H", i32), ("W", i32), ("C1", i32), ("C2", i32), ("N", i32),
                 ("KH", i32), ("stride", i32), ("upsample", i32), ("act", i32), ("transpose_out", i32), ("ldt", i32),
                 ("out_f32", i32), ("dtype", i32), ("scale", f32), ("rowvec_ld", i32), ("workspace", vp),
-                ("workspace_bytes", C.c_int64), ("row_stats", vp), ("colsum", vp), ("tile", i32), ("split", i32), ("pad_br", i32), ("up_h", i32), ("up_w", i32)]
+                ("workspace_bytes", C.c_int64), ("row_stats", vp), ("colsum", vp), ("tile", i32), ("split", i32), ("pad_br", i32),
+                ("prefetch", vp), ("prefetch_bytes", C.c_int64), ("up_h", i32), ("up_w", i32)]
 
 
 class GroupNormArgs(C.Structure):

@@ -349,7 +349,10 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
                                                                         const int NT, const int nwg, const int tile0) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  // [256 B per wave: landing zone of the weight prefetch (sr_igemm_args.prefetch), never read] [bias / colsum rows] [ring]
+  constexpr int PF_B = WAVES_M * WAVES_N * 256;
+  char* const smem_raw = smem_all + PF_B;
   // fp16, unsplit: the tile's bias and colsum rows (2 x BN floats) sit in front of the staging ring, fetched by LDS-DMA below
   constexpr bool VECPRE = sizeof(T) == 2 && !SPLIT;
   constexpr int VEC_B = VECPRE ? 2 * BN * 4 : 0;
@@ -373,6 +376,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
   unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0};
 #endif
   SR_TS(0);
+  if (p.prefetch) {
+    const int64_t nthr = (int64_t)gridDim.x * gridDim.y * (NW * 64);
+    sr_prefetch_touch(p.prefetch, p.prefetch_bytes, ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NW * 64) + tid, nthr,
+                      __builtin_amdgcn_readfirstlane(sr_lds_addr(smem_all) + wv * 256));
+  }
   const int wg = tile0 + sr_xcd_remap(blockIdx.x, nwg);      // this launch covers tiles [tile0, tile0 + nwg)
   const int mt = wg / NT, nt = wg - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -681,7 +689,8 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   constexpr int lds_stage = STAGES * (BM + BN) * BKB;
   constexpr int lds_epi_all = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);   // fp32 output sub-tiles of all waves
   constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
-  constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0);   // + the bias / colsum rows (fp16 kernels)
+  constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0)    // + the bias / colsum rows (fp16 kernels)
+                      + WAVES_M * WAVES_N * 256;                                                           // + the prefetch landing zone
   auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB, SPREAD, MINB>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
@@ -757,7 +766,7 @@ int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int tile0, int S
   const int MT = (M + BM - 1) / BM, NTv = (a.N + BN - 1) / BN, ntiles = MT * NTv, ntail = ntiles - tile0;
   constexpr int lds_stage = 2 * (BM + BN) * 128;
   constexpr int lds_epi = 4 * (BM / 2) * ((BN / 2) * 4 + 16);
-  constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0);   // (the unsplit head tiles' bias / colsum rows)
+  constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0) + 4 * 256;   // (the unsplit head tiles' bias / colsum rows, the prefetch landing zone)
   auto kf = igemm_kernel<T, BM, BN, 2, 2, 2, false, false>;
   auto ks = igemm_kernel<T, BM, BN, 2, 2, 2, false, true>;
   static bool attr_set = false;
@@ -788,11 +797,15 @@ int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int tile0, int S
 //   tap loop is unrolled).
 __global__ __launch_bounds__(512, 1) void conv3p_kernel(const sr_igemm_args p, const int M, const int NT, const int nwg) {
   using T = _Float16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  char* const smem = smem_all + 8 * 256;               // (in front: the prefetch landing zone, 256 B per wave)
   constexpr int BM = 256, BN = 320, WAVES_M = 4, WAVES_N = 2, TM = 4, TN = 10;
   constexpr int APITCH = 80, ABYTES = 32768, BBYTES = BN * 64, BOFF = 2 * ABYTES, LDS_TOTAL = BOFF + 4 * BBYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (p.prefetch)
+    sr_prefetch_touch(p.prefetch, p.prefetch_bytes, (int64_t)blockIdx.x * 512 + tid, (int64_t)gridDim.x * 512,
+                      __builtin_amdgcn_readfirstlane(sr_lds_addr(smem_all) + wv * 256));
   const int wg = sr_xcd_remap(blockIdx.x, nwg);
   const int mt = wg / NT, nt = wg - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -936,7 +949,7 @@ static bool conv3p_ok(const sr_igemm_args& a, int M) {
 }
 
 static int launch_conv3p(const sr_igemm_args& a, int M, hipStream_t st) {
-  constexpr int lds = 2 * 32768 + 4 * 320 * 64;
+  constexpr int lds = 2 * 32768 + 4 * 320 * 64 + 8 * 256;
   const int NT = a.N / 320, nwg = (M / 256) * NT;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
@@ -948,10 +961,12 @@ static int launch_conv3p(const sr_igemm_args& a, int M, hipStream_t st) {
 // Wave quantisation model for the 4-wave tiles (calibrated on MI355X): `slots` workgroups are co-resident
 // chip-wide, a round of co-resident workgroups takes t_k microseconds per K-step, partials cost their HBM round trip.
 // Returns the split count for the tail round (1 = none) and sets tile0 (tiles before it run unsplit).
-static inline int plan_split(int64_t tiles, int KT, int slots, double t_k, int64_t tile_ws_bytes, int64_t ws_bytes, int* tile0) {
+static inline int plan_split(int64_t tiles, int KT, int slots, double t_k, int64_t tile_ws_bytes, int64_t ws_bytes, int* tile0, int forceS = 0) {
   const int64_t full = tiles / slots, tail = tiles - full * slots;
   *tile0 = (int)(full * slots);
   if (tail == 0) return 1;
+  if (forceS > 0)                                            // sr_igemm_args.split = S: the per-shape tuner measures S instead of modelling it
+    return (KT / forceS >= 4 && (int64_t)forceS * tail * tile_ws_bytes <= ws_bytes) ? forceS : -1;
   if (const char* fs = getenv("SR_SPLIT_S")) {               // tuning aid: force the split count of the tail round
     const int S = atoi(fs);
     if (S >= 1 && KT / S >= 4 && (int64_t)S * tail * tile_ws_bytes <= ws_bytes) return S;
@@ -976,17 +991,23 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int force = fenv ? atoi(fenv) : a.tile;              // 1=256x128x3, 2=128x128, 3=128x64, 4=64x64, 5=256x320
   static const bool split_off = getenv("SR_SPLITK") && atoi(getenv("SR_SPLITK")) == 0;      // tuning / A-B aid
   const int KT = a.KH * a.KH * ((a.C1 + a.C2) / (int)(128 / sizeof(T)));
-  const bool may_split = !TRANS && !split_off && a.split == 0 && a.workspace && a.act != 2 && a.N % 4 == 0 && KT >= 32;
+  const int forceS = a.split > 1 ? a.split : 0;
+  const bool may_split = !TRANS && !split_off && a.split >= 0 && a.workspace && a.act != 2 && a.N % 4 == 0 && KT >= 32;
+  if (forceS && (!may_split || (force != 2 && force != 3)))
+    SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d needs tile 2 or 3, a workspace, no GEGLU / transposed output and K >= 32 steps", a.split);
   if constexpr (!TRANS) {
-    if (may_split && (force == 2 || force == 3)) {           // tuned tile + modelled tail split
+    if (may_split && (force == 2 || force == 3)) {           // tuned tile + modelled (split 0) or given (split S) tail split
       int tile0 = 0;
       if (force == 2) {
-        const int S = plan_split(wg_128x128, KT, 512, 1.2, 128 * 128 * 4, a.workspace_bytes, &tile0);
+        const int S = plan_split(wg_128x128, KT, 512, 1.2, 128 * 128 * 4, a.workspace_bytes, &tile0, forceS);
+        if (S < 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d does not fit this shape (K steps %d, workspace %lld B)", a.split, KT, (long long)a.workspace_bytes);
         if (S > 1) return launch_split<T, 128, 128>(a, M, Ho, Wo, tile0, S, st);
       } else {
-        const int S = plan_split((int64_t)((M + 127) / 128) * n64, KT, 768, 0.93, 128 * 64 * 4, a.workspace_bytes, &tile0);
+        const int S = plan_split((int64_t)((M + 127) / 128) * n64, KT, 768, 0.93, 128 * 64 * 4, a.workspace_bytes, &tile0, forceS);
+        if (S < 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d does not fit this shape (K steps %d, workspace %lld B)", a.split, KT, (long long)a.workspace_bytes);
         if (S > 1) return launch_split<T, 128, 64>(a, M, Ho, Wo, tile0, S, st);
       }
+      if (forceS) SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d: nothing to split (whole rounds of workgroups only)", a.split);
     }
   }
   if (force == 2) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
@@ -1095,7 +1116,7 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
   if (a->row_stats && !a->colsum) SR_FAIL(SR_ERR_INVALID, "sr_igemm: row_stats without colsum");
   if (a->row_stats && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
-  if (a->tile < 0 || a->tile > 12 || (a->split != 0 && a->split != -1)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
+  if (a->tile < 0 || a->tile > 12 || a->split < -1 || a->split == 1 || a->split > 16) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample && ((a->up_h > 0) != (a->up_w > 0))) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w go together");
   if (!a->upsample && (a->up_h || a->up_w)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w without upsample");

@@ -130,6 +130,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
   float* sh = sc + C;
   float* gm = sh + C;      // [groups] mean, [groups] rstd
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int ppc = gn_ppc(HW);
+  const int p0 = chunk * ppc;
+  const int p1 = min(HW, p0 + ppc);
+  const int total = (p1 - p0) * cpt;
+  auto src_of = [&](int idx, int& c0, int& p) -> const T* {
+    p = p0 + idx / cpt;
+    c0 = (idx - (idx / cpt) * cpt) * EPC;
+    return c0 < C1 ? x1 + ((int64_t)b * HW + p) * C1 + c0 : x2 + ((int64_t)b * HW + p) * C2 + (c0 - C1);
+  };
+  auto finish = [&](float (&v)[EPC], int c0, int p) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float t = v[e] * sc[c0 + e] + sh[c0 + e];
+      v[e] = silu ? sr_silu_f(t) : t;
+    }
+    store_chunk<T>(y + ((int64_t)b * HW + p) * C + c0, v);
+  };
+  // The block's first trip of data loads goes out BEFORE the statistics preamble (partials reduction, two barriers, scale /
+  // shift table): at 64 pixels per block the preamble re-reads 16 KB of partials to process 20 KB of activations and used to
+  // sit, latency-exposed, in front of the first load (UNet 64x64 maps: 32 -> ~20 us per launch).  The arithmetic is unchanged.
+  // (raw 16-byte vectors, converted after the preamble behind an opaque asm so that no wait for them is placed earlier)
+  using VEC = typename std::conditional<sizeof(T) == 2, h16x8, f32x4>::type;
+  VEC pr[4];
+  int pc0[4], pq0[4];
+  int pre_n = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pr[i] = VEC{};
+    if (tid + i * 256 < total) { pr[i] = *(const VEC*)src_of(tid + i * 256, pc0[i], pq0[i]); pre_n = i + 1; }
+  }
   // fixed-order reduction of this batch entry's partials, spread over the whole block: thread (g, part) sums every
   // 8th chunk, then thread g adds the 8 parts in order (bit-reproducible, no serial latency chain)
   {
@@ -160,24 +190,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
     sc[c] = a; sh[c] = beta[c] - gm[g] * a;
   }
   __syncthreads();
-  const int ppc = gn_ppc(HW);
-  const int p0 = chunk * ppc;
-  const int p1 = min(HW, p0 + ppc);
-  const int total = (p1 - p0) * cpt;
-  auto src_of = [&](int idx, int& c0, int& p) -> const T* {
-    p = p0 + idx / cpt;
-    c0 = (idx - (idx / cpt) * cpt) * EPC;
-    return c0 < C1 ? x1 + ((int64_t)b * HW + p) * C1 + c0 : x2 + ((int64_t)b * HW + p) * C2 + (c0 - C1);
-  };
-  auto finish = [&](float (&v)[EPC], int c0, int p) {
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      float t = v[e] * sc[c0 + e] + sh[c0 + e];
-      v[e] = silu ? sr_silu_f(t) : t;
-    }
-    store_chunk<T>(y + ((int64_t)b * HW + p) * C + c0, v);
-  };
   int idx = tid;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                            // the trip whose loads were issued before the preamble
+    VEC r = pr[i];
+    asm volatile("" : "+v"(r));
+    if (i < pre_n) {
+      float v[EPC];
+      load_chunk<T>((const T*)&r, v);
+      finish(v, pc0[i], pq0[i]);
+    }
+  }
+  idx += pre_n * 256;
   for (; idx + 3 * 256 < total; idx += 4 * 256) {          // four 16-byte loads in flight per lane
     int c0[4], pq[4];
     float v0[EPC], v1[EPC], v2[EPC], v3[EPC];
@@ -402,6 +426,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   }
 }
 
+// Sub-wave rows: LPR lanes per row (a power of two), NCH 16-byte chunks per lane -- for C = LPR * NCH chunks.  The wave-per-row
+// form above leaves 24 of 64 lanes idle at C = 320 (40 chunks) and runs two 6-step shuffle trees per row; here a wave owns
+// 64 / LPR rows at once (C 320: eight rows of 8 lanes x 5 chunks), every lane is busy, each row's 128-byte pieces are read by
+// LPR consecutive lanes (whole lines), NCH independent loads are in flight per lane and the trees are log2(LPR) steps.
+// Mean then centred second moment, as above.
+template <typename T, int LPR, int NCH>
+__global__ __launch_bounds__(256) void layernorm_sub_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ y, int rows, int C, float eps) {
+  constexpr int EPC = sr_traits<T>::EPC, RPW = 64 / LPR;
+  using VEC = typename std::conditional<sizeof(T) == 2, h16x8, f32x4>::type;
+  const int lane = threadIdx.x & 63, sub = lane & (LPR - 1);
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool on = row < rows;
+  VEC raw[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) raw[i] = on ? *(const VEC*)(x + (int64_t)row * C + (sub + i * LPR) * EPC) : VEC{};
+  float v[NCH][EPC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    load_chunk<T>((const T*)&raw[i], v[i]);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s += v[i][e];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { const float d = v[i][e] - mean; q += d * d; }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if (!on) return;
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (sub + i * LPR) * EPC;
+    float o[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+    store_chunk<T>(y + (int64_t)row * C + c0, o);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int rows, int C, float eps) {
   constexpr int EPC = sr_traits<T>::EPC;
@@ -506,6 +576,35 @@ extern "C" int sr_layernorm(const void* x, const float* gamma, const float* beta
   };
   using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+  // sub-wave rows when the chunk count factors as (power of two <= 32) x (1..5): every UNet / VAE width does
+  static const bool no_sub = getenv("SR_LN_WAVE_ROWS") != nullptr;       // tuning / A-B aid
+  auto sub = [&](auto t) -> bool {
+    using T = decltype(t);
+    if (no_sub) return false;
+    for (int nch = 5; nch >= 1; --nch) {
+      if (cpt % nch) continue;
+      const int lpr = cpt / nch;
+      if (lpr > 32 || (lpr & (lpr - 1))) continue;
+      const dim3 grid(sr_cdiv(rows, 4 * (64 / lpr)));
+#define SR_LN_SUB(L, N) hipLaunchKernelGGL((layernorm_sub_kernel<T, L, N>), grid, dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, eps); return true
+#define SR_LN_SUBN(L) switch (nch) { case 1: SR_LN_SUB(L, 1); case 2: SR_LN_SUB(L, 2); case 3: SR_LN_SUB(L, 3); case 4: SR_LN_SUB(L, 4); default: SR_LN_SUB(L, 5); }
+      switch (lpr) {
+        case 1: SR_LN_SUBN(1)
+        case 2: SR_LN_SUBN(2)
+        case 4: SR_LN_SUBN(4)
+        case 8: SR_LN_SUBN(8)
+        case 16: SR_LN_SUBN(16)
+        default: SR_LN_SUBN(32)
+      }
+#undef SR_LN_SUBN
+#undef SR_LN_SUB
+    }
+    return false;
+  };
+  if ((dtype == SR_F16 && sub(_Float16())) || (dtype == SR_F32 && sub(float()))) {
+    SR_CHECK_LAUNCH("sr_layernorm");
+    return SR_OK;
+  }
   if (dtype == SR_F16) {
     if (cpt <= 64) go(_Float16(), I1{}, I4{}); else if (cpt <= 128) go(_Float16(), I2{}, I2{});
     else if (cpt <= 192) go(_Float16(), I3{}, I2{}); else go(_Float16(), I5{}, I1{});

@@ -66,6 +66,20 @@ __device__ __forceinline__ void sr_glds16_asm_nosave(const void* gsrc, unsigned 
 __device__ __forceinline__ void sr_glds16_asm_saddr(unsigned voff, const void* sbase, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
+// Cache warm-up of bytes a LATER launch will stream (sr_igemm_args.prefetch): the threads of the grid share the range, one
+// 4-byte LDS-DMA read per 64 bytes into a 256-byte per-wave scratch nobody reads (no VGPR destination, so nothing the compiler
+// could reuse while the load is in flight).  These are the oldest vector-memory requests of the wave: every counted
+// s_waitcnt vmcnt(N) that follows also covers them (requests retire in issue order).
+__device__ __forceinline__ void sr_prefetch_touch(const void* base, int64_t bytes, int64_t gtid, int64_t gthreads, unsigned lds_scratch_wave) {
+  const int64_t n = bytes >> 6;                              // 64-byte sectors
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0" : "=&s"(keep) : "s"(lds_scratch_wave));
+  for (int64_t i = gtid; i < n; i += gthreads) {
+    const char* src = (const char*)base + (i << 6);
+    asm volatile("global_load_lds_dword %0, off" ::"v"(src) : "memory");
+  }
+  asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
+}
 __device__ __forceinline__ unsigned sr_lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }

@@ -182,4 +182,8 @@ def controlnet_names_shapes(cfg, hint_channels=3):
     for i, c in enumerate(zc):
         out += [(f"zero_convs.{i}.0.weight", (c, c, 1, 1)), (f"zero_convs.{i}.0.bias", (c,))]
     out += [("middle_block_out.0.weight", (ch, ch, 1, 1)), ("middle_block_out.0.bias", (ch,))]
+    # the reference module's state_dict() order (cldm.py registers zero_convs and input_hint_block before middle_block): seeded
+    # synthetic weights are drawn per position in this table, so the order is part of the contract with the golden vectors
+    rank = {"time_embed": 0, "input_blocks": 1, "zero_convs": 2, "input_hint_block": 3, "middle_block": 4, "middle_block_out": 5}
+    out = [e for _, e in sorted(enumerate(out), key=lambda ie: (rank[ie[1][0].split(".")[0]], ie[0]))]
     return out, norm_out

@@ -80,6 +80,42 @@ class BoatScene:
         ]
 
 
+class MultiObjScene:
+    """BASELINE config 5's scene (scripts/multi_obj_example.py:24-52): a loaded mesh at the origin turning about Y
+    (AutoRotation 4 deg x DeltaTime; the headless driver fixes the pose per frame), a textured sphere at (-1.5, 0.5, 1.0)
+    scale 0.5 and a textured plane of scale 5, CameraController start pose (4, 3.5, 4) -> (0, 0.4, 0).  The shipped script only
+    rasterises (``disableComfyUI=True``); the bake composition around it is the one of the reference's bake scripts
+    (scripts/bake_ball.py:36-55): a corr-map proxy sphere about the turning object -- k x k maps, texcoord ids, BAKING mode,
+    TRANSPARENT queue -- which is what ties the views of one call together."""
+
+    def __init__(self, obj_path, W=512, H=512, k=6, seed=0, device="cuda", deg_per_frame=4.0, proxy_scale=1.6):
+        self.W, self.H, self.k = W, H, k
+        self.camera = S.Camera((4.0, 3.5, 4.0), (0, 0.4, 0), fov=45.0, near=0.1, far=100.0)
+        self.mesh = S.Mesh.Load(obj_path)
+        self.sphere, self.plane = S.Mesh.Sphere(32), S.Mesh.Plane()
+        g = torch.Generator().manual_seed(seed)
+        self.noise_tex = torch.randn(512, 512, 4, generator=g).half().to(device)
+        self.diffuse = torch.rand(64, 64, 4, generator=g).to(device)
+        self.diffuse[..., 3] = 1.0
+        checker = ((torch.arange(64)[:, None] // 8 + torch.arange(64)[None, :] // 8) % 2).float()
+        self.debug_tex = torch.stack([checker, 1 - checker, checker * 0 + 0.5, checker * 0 + 1.0], -1).contiguous().to(device)
+        self.corrmap = CorrespondMap(k=k, height=H, width=W, device=device)
+        self.sprite, self.material = 4, 4
+        self.deg_per_frame, self.proxy_scale = deg_per_frame, proxy_scale
+
+    def tasks(self, frame):
+        rot = S.rotate_y(self.deg_per_frame * float(frame))
+        ball = S.matmul(S.translate((-1.5, 0.5, 1.0)), S.scale(0.5))
+        return [
+            S.DrawTask(self.mesh, rot, sprite_id=1, material_id=1, render_mode=0, diffuse_tex=self.diffuse, order=999.80),
+            S.DrawTask(self.sphere, ball, sprite_id=2, material_id=2, render_mode=0, diffuse_tex=self.debug_tex, order=999.85),
+            S.DrawTask(self.plane, S.scale(5.0), sprite_id=3, material_id=3, render_mode=0, diffuse_tex=self.debug_tex, order=999.83),
+            S.DrawTask(self.sphere, S.matmul(rot, S.scale(self.proxy_scale)), sprite_id=self.sprite, material_id=self.material,
+                       render_mode=2, corrmap_k=self.k, use_texcoord_id=True, id_size=(self.W, self.H), noise_tex=self.noise_tex,
+                       order=2000.2),
+        ]
+
+
 class CallOrder:
     """Tickets for the two sections of a call that touch process-wide state — the draws on the global CPU generator at the
     start of sampling and the frame-ordered ('first' priority) corr-map update — so that calls in flight on several streams

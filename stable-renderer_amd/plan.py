@@ -83,6 +83,11 @@ class PlanBuilder:
         # projections beside the main chain) it is neutral under a hipGraph (24.15 vs 24.00 ms) and costs 1 ms eagerly
         # (60 event record/wait pairs); SR_TWO_LANES=1 turns it on.
         self.two_lanes = os.environ.get("SR_TWO_LANES", "0") == "1"
+        # every igemm warms the Infinity Cache with the packed weights of the NEXT igemm of the plan (sr_igemm_args.prefetch): one
+        # UNet evaluation streams 1.7 GB of weights, so none of them survives in the 256 MB cache from one evaluation to the next
+        # and each layer would fetch its own from HBM on its critical path.  SR_PREFETCH=0 turns it off (A/B aid)
+        self.prefetch = os.environ.get("SR_PREFETCH", "1") != "0"
+        self._prev_igemm = None
 
     # ---- side lane (include/sr_hip.h: SR_OP_FORK / SR_OP_JOIN) -----------------------------------------
     def fork(self):
@@ -134,6 +139,11 @@ class PlanBuilder:
         if O.autotune_enabled():
             O.tune_igemm(ar, allow_split=self._lane == 0)
         self._emit(L.OP_IGEMM, "igemm", ar)
+        if self.prefetch and w.is_cuda:
+            prev, self._prev_igemm = self._prev_igemm, self.ops[-1]
+            if prev is not None and prev.u.igemm.w != w.data_ptr():
+                prev.u.igemm.prefetch = w.data_ptr()
+                prev.u.igemm.prefetch_bytes = min(w.numel() * w.element_size(), 48 << 20)
         KH, st, up = kw.get("KH", 1), kw.get("stride", 1), kw.get("upsample", 0)
         Ho, Wo = (tuple(kw["up_hw"]) if kw.get("up_hw") else (2 * H, 2 * W)) if up else ((H + st - 1) // st, (W + st - 1) // st)
         f = 2 * B * Ho * Wo * N * KH * KH * (C1 + kw.get("C2", 0))
@@ -219,4 +229,5 @@ class PlanBuilder:
         p = Plan(self.ops, list(self.keep), self.op_flops)
         self.ops = []
         self.op_flops = []
+        self._prev_igemm = None
         return p

@@ -292,7 +292,7 @@ def test_groupnorm(ops, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("Cc", [64, 320, 1280])
+@pytest.mark.parametrize("Cc", [64, 128, 320, 640, 1280])
 def test_layernorm(ops, dtype, Cc):
     x = rnd(1, 3, 37, Cc) * 2 + 0.5
     gamma, beta = 1 + 0.1 * rnd(2, Cc), 0.1 * rnd(3, Cc)

@@ -26,6 +26,12 @@ def test_model_key_enumeration_matches_reference_state_dicts():
     ns, norms = vae_decoder_names_shapes()
     assert [(n, list(s)) for n, s in ns] == [(n, list(s)) for n, s in k["names_shapes"]]
     assert sorted(norms) == sorted(k["norm_names"])
+    from stable_renderer_amd.model_shapes import controlnet_names_shapes
+    with open(os.path.join(GOLD, "controlnet_tiny_keys.json")) as f:          # cldm.ControlNet.state_dict() order (seed positions)
+        k = json.load(f)
+    ns, norms = controlnet_names_shapes(dict(SD15_CFG, model_channels=64, context_dim=64))
+    assert [(n, list(s)) for n, s in ns] == [(n, list(s)) for n, s in k["names_shapes"]]
+    assert sorted(norms) == sorted(k["norm_names"])
     from stable_renderer_amd.model_shapes import vae_encoder_names_shapes
     with open(os.path.join(GOLD, "vae_enc_keys.json")) as f:
         k = json.load(f)
