@@ -22,6 +22,7 @@ Writes tests/golden/raster_pin.npz: recovered matrices, the recorded agreement, 
 the oracle (CPU) and tests/test_gpu_raster.py against the HIP rasterizer (GPU).
 
 Run:  python oracle/pin_raster.py        (needs /root/reference; a few seconds)
+      python oracle/pin_raster.py planes (the normal / depth planes of the same dumps -> tests/golden/raster_pin_planes.npz)
 """
 import os
 import sys
@@ -166,5 +167,76 @@ def main():
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "planes" not in sys.argv[1:]:
     main()
+
+
+# ---- the other planes the reference dumped for the same scene -------------------------------------------
+# normal/ (RGBA8 = n * 0.5 + 0.5, default_Gbuffer.frag.glsl:114-123) and depth/ (1 - gl_FragCoord.z, :111, min-max normalised
+# over the frame by DiffusionManager._outputDepthMap, diffusionManager.py:231-254).  A plane can be pinned only on a frame
+# whose pos/ + id/ dumps exist too (they give the model-view): normal 50, depth 50 / 31 / 8.  What the other directories hold:
+# noise/ is all zero (the sphere carries no noise texture: hasNoiseTex == 0 -> outNoise = 0, frag:102-103 -- ours writes the
+# same zeros); canny/ holds single-channel 0 / 255 edge images with ~19 000 edge pixels inside the disk, i.e. cv2.Canny of the
+# colour image (the `ai_canny` output, diffusionManager.py:261-275), not the shader's plane: with this camera the view normal's
+# z never drops under cos(80 deg) on the visible cap (n_z >= r / distance = 0.29), so the shader plane is empty for this scene
+# in the reference and here alike; normal_2.png does not belong to the pose of pos_2 / id_2 (mean abs difference 113 / 255).
+PLANE_FRAMES = dict(normal=(50,), depth=(50, 31, 8))
+
+
+def planes_of(MV, P, mesh_uv):
+    """-> (coverage, normal RGB uint8, depth gray uint8, depth alpha) of the oracle's normal+depth plane in the dump's encoding"""
+    import raster_ref as R
+    from stable_renderer_amd import scene as S
+    g = R.GBufferRef(512, 512)
+    g.clear()
+    t = S.DrawTask(mesh_uv, np.eye(4, dtype=np.float32), sprite_id=1, material_id=1, render_mode=0, use_texcoord_id=True, id_size=(TEX, 0))
+    g.draw(t, dict(MV=MV.reshape(-1), MV_IT=S.inverse_transpose(MV).reshape(-1), P=P.reshape(-1), depth_test=1))
+    return (g.id[..., 0] != 0,) + encode_planes(g.normal_depth.view(np.float16).astype(np.float32))
+
+
+def encode_planes(nd):
+    """normal+depth plane (H, W, 4) fp32 -> what _outputMap / _outputDepthMap write: (normal RGB uint8, gray uint8, alpha bool)"""
+    normal = (nd[..., :3] * 255).astype(np.uint8)
+    dep = nd[..., 3]
+    dmax, dmin = dep.max(), dep[dep > 0].min()
+    dn = (dep - dmin) / (dmax - dmin)
+    return normal, (np.clip(dn, 0, 1) * 255).astype(np.uint8), dn > 0
+
+
+def main_planes():
+    from PIL import Image
+    from stable_renderer_amd import scene as S
+    P = S.perspective(np.radians(45.0), 1.0, 0.1, 100.0)
+    mesh_uv, mesh_vu = sphere_meshes()
+    frames = sorted({f for fs in PLANE_FRAMES.values() for f in fs})
+    out = dict(P=P, frames=np.asarray(frames), row_stride=np.asarray(ROW_STRIDE))
+    rows = np.arange(0, 512, ROW_STRIDE)
+    for fr in frames:
+        MV, st, cov, pos, ids = fit_frame(fr, mesh_uv, mesh_vu, P, verbose=False)
+        out[f"MV_{fr}"] = MV
+        out[f"cov_{fr}"] = np.packbits(cov)
+        ocov, on, og, oa = planes_of(MV, P, mesh_uv)
+        both = cov & ocov
+        if fr in PLANE_FRAMES["normal"]:
+            n = np.asarray(Image.open(f"{REF}/normal/normal_{fr}.png"))
+            d = np.abs(on[both].astype(np.int32) - n[..., :3][both].astype(np.int32)).max(-1)
+            print(f"normal {fr}: within 1/255 on {float((d <= 1).mean()):.4f} of the covered pixels, max {int(d.max())}")
+            out[f"normal_{fr}"] = n[rows][cov[rows]][:, :3].copy()
+            assert (n[..., :3][~cov] == 0).all() and (n[..., 3] == 255).all()
+        if fr in PLANE_FRAMES["depth"]:
+            dref = np.asarray(Image.open(f"{REF}/depth/depth_{fr}.png"))
+            dd = np.abs(og[both].astype(np.int32) - dref[..., 0][both].astype(np.int32))
+            print(f"depth {fr}: within 2/255 on {float((dd <= 2).mean()):.4f}, within 4/255 on {float((dd <= 4).mean()):.4f}, "
+                  f"alpha agrees on {float((oa == (dref[..., 3] > 0)).mean()):.5f}")
+            out[f"depth_{fr}"] = dref[rows][cov[rows]][:, 0].copy()
+            out[f"depth_alpha_{fr}"] = np.packbits(dref[..., 3] > 0)
+            assert (dref[..., 0] == dref[..., 1]).all() and (dref[..., 0] == dref[..., 2]).all()
+        nz = np.load(f"{REF}/noise/noise_{fr}.npy") if os.path.exists(f"{REF}/noise/noise_{fr}.npy") else None
+        assert nz is None or not nz.any()
+    dst = os.path.join(ROOT, "tests", "golden", "raster_pin_planes.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst) // 1024, "KiB")
+
+
+if __name__ == "__main__" and "planes" in sys.argv[1:]:
+    main_planes()

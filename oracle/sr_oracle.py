@@ -689,6 +689,19 @@ def prepare_cond_entries(pos, neg, h, w):
 
 # ------------------------------------------------------------------------------------------------------
 # ControlNet (comfy/cldm/cldm.py:284-311) + control_merge (comfy/controlnet.py:95-141)
+def common_upscale_center(x, width, height):
+    """comfy.utils.common_upscale(x, width, height, 'nearest-exact', 'center') (comfy/utils.py:418-443): what ControlNet.get_control
+    does to the WHOLE hint image when the model call runs on a cropped conditioning area (comfy/controlnet.py:193-201)"""
+    ow, oh = x.shape[3], x.shape[2]
+    old_aspect, new_aspect = ow / oh, width / height
+    cx = cy = 0
+    if old_aspect > new_aspect:
+        cx = round((ow - ow * (new_aspect / old_aspect)) / 2)
+    elif old_aspect < new_aspect:
+        cy = round((oh - oh * (old_aspect / new_aspect)) / 2)
+    return F.interpolate(x[:, :, cy:oh - cy, cx:ow - cx], size=(height, width), mode="nearest-exact")
+
+
 def controlnet_forward(sd, cfg, x, hint, t, ctx, strength=1.0):
     """-> dict(output=[12 tensors], middle=[1 tensor]) as consumed by unet_forward(control=...)"""
     mc, heads = cfg["model_channels"], cfg["num_heads"]

@@ -92,6 +92,19 @@ def encode_adm_sdxl(pooled_output, width, height, crop_w=0, crop_h=0, target_wid
     return torch.cat((pooled_output.to(flat.device).float(), flat), dim=1)
 
 
+def _common_upscale_center(x, width, height):
+    """comfy.utils.common_upscale(samples, width, height, 'nearest-exact', 'center') (comfy/utils.py:418-443): centre crop to the
+    target aspect ratio, then nearest-exact resize.  x (N,C,H,W)"""
+    ow, oh = x.shape[3], x.shape[2]
+    old_aspect, new_aspect = ow / oh, width / height
+    cx = cy = 0
+    if old_aspect > new_aspect:
+        cx = round((ow - ow * (new_aspect / old_aspect)) / 2)
+    elif old_aspect < new_aspect:
+        cy = round((oh - oh * (old_aspect / new_aspect)) / 2)
+    return torch.nn.functional.interpolate(x[:, :, cy:oh - cy, cx:ow - cx], size=(height, width), mode="nearest-exact")
+
+
 class SamplingCallbackContext:
     """comfyUI/types/runtime.py:543-593 (fields a corresponder reads)."""
 
@@ -262,15 +275,6 @@ class DiffusionRunner:
                              out_u=torch.empty_like(self.x), cnt_u=torch.empty_like(self.x))
         return self._general
 
-    def _check_general(self, n_rand):
-        """the combinations the general path does not run -- checked on EVERY sample() call, not only when the group list is
-        first built (a later call may add K/V injection or ControlNets to a cached list)"""
-        groups = self._general["groups"]
-        if n_rand is not None and len(groups) != 1:
-            raise NotImplementedError("K/V injection (OverlapCorresponder) with conditioning areas that need several model calls")
-        if self.controlnets and any(g["area"] != (self.h, self.w, 0, 0) for g in groups):
-            raise NotImplementedError("ControlNets with conditioning areas (the hint would need the same crop)")
-
     def _general_plans(self, inject):
         """build (once per injected-frame COUNT) and load the plans of the general path"""
         G = self._general
@@ -309,6 +313,13 @@ class DiffusionRunner:
                     raise ValueError("ControlNets are attached: call set_control_hints() before sampling")
                 for cp, hint in zip(p["cn"]["plans"], self._hints):
                     hv = hint.to(cp["hint"].device, torch.float32)
+                    th, tw = cp["hint"].shape[2], cp["hint"].shape[3]
+                    if (hv.shape[2], hv.shape[3]) != (th, tw):
+                        # a model call on a conditioning AREA: the control net gets the cropped latent, and ControlNet.get_control
+                        # resizes the WHOLE hint to 8x that crop (common_upscale(cond_hint_original, w*8, h*8, 'nearest-exact',
+                        # 'center'), comfy/controlnet.py:193-201, comfy/utils.py:418-443) -- it does not cut the window out of it.
+                        # Done once per sampling run, as the reference caches it per size.
+                        hv = _common_upscale_center(hv, tw, th)
                     for j in range(g["chunks"]):
                         cp["hint"][j * N:(j + 1) * N].copy_(hv.expand(N, -1, -1, -1) if hv.shape[0] == 1 else hv)
                     cp["prologue"].run()
@@ -468,7 +479,6 @@ class DiffusionRunner:
             if general:
                 n_rand_ = inject_n_rand if (inject_n_rand is not None and inject_n_rand >= 0) else None
                 G = self._general if self._general is not None else self._build_general(n_rand_)
-                self._check_general(n_rand_)
             inject = None
             if inject_n_rand is not None and inject_n_rand >= 0:
                 n_all = self.N if self.shard is None else self.shard.n_views

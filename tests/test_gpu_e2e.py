@@ -367,3 +367,114 @@ def test_masked_text_nodes_feed_the_sampler():
     a = N.custom_ksampler(model, 5, 2, 4.0, "euler", "normal", pos, neg, lat)[0]["samples"]
     b = N.custom_ksampler(model, 5, 2, 4.0, "euler", "normal", [pos[3]], neg, lat)[0]["samples"]
     assert torch.isfinite(a).all() and (a - b).abs().max().item() > 1e-3
+
+
+def _first_injected_index(rng_seed, noise_shape, B0):
+    """the index pre_atten_inject draws on the run's first UNet call, from the global generator in the reference's order:
+    custom_ksampler's seed, 'ddim' reseeding with seed + 1 and drawing one noise tensor, then randint(1, B0)"""
+    torch.manual_seed(rng_seed)
+    seed = int(torch.randint(0, 2 ** 32, (1,)).item())
+    g = torch.manual_seed(seed + 1)
+    torch.randn(noise_shape, generator=g, device="cpu")
+    return int(torch.randint(1, B0, (1,)).item())
+
+
+def test_kv_injection_with_several_model_calls_vs_oracle():
+    """OverlapCorresponder + conditioning AREAS: calc_cond_uncond_batch makes several model calls per step, every one of them
+    runs the UNet with the corresponder, and the indices drawn on the FIRST call (randint(1, batch of that call),
+    corresponder.py:204-205) are reused by the others -- k_context[idx] raises IndexError in a smaller batch (:207-214).
+    Both outcomes against the oracle (was NotImplementedError until round 3)"""
+    import sr_oracle as ORC
+    from stable_renderer_amd import ops as O
+    from stable_renderer_amd.conditioning import entries_of
+    from stable_renderer_amd.sampling import DiffusionRunner
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    sd = _sd("unet_tiny_keys.json", 1)
+    net = UNet(sd, cfg, dtype=torch.float32)
+    N, h, w = 2, 16, 24
+    pos, neg, scale = _cond_lists(64, h * 8, w * 8)["areas"]
+    g = torch.Generator().manual_seed(21)
+    noise = torch.randn(N, 4, h, w, generator=g)
+    ids = torch.zeros(N, h * 8, w * 8, 4, dtype=torch.int32)
+    ids[..., 0] = 1
+    ids[..., 3] = torch.randint(0, 400, (N, h * 8, w * 8), generator=g, dtype=torch.int32)
+    ids[torch.rand(N, h * 8, w * 8, generator=g) < 0.2] = 0
+    idx = O.OverlapIndex(ids.cuda(), h, w)
+    run = DiffusionRunner(net, N, h, w, scale, n_ctx=77, use_graph=False)
+    run.set_cond_entries(entries_of(pos), entries_of(neg))
+    B0 = N * run._build_general(1)["groups"][0]["chunks"]
+    Bmin = N * min(gr["chunks"] for gr in run._general["groups"])
+    assert len(run._general["groups"]) > 1 and Bmin < B0
+    ok_seed = next(s_ for s_ in range(100) if _first_injected_index(s_, tuple(noise.shape), B0) < Bmin)
+    bad_seed = next(s_ for s_ in range(100) if _first_injected_index(s_, tuple(noise.shape), B0) >= Bmin)
+
+    def cb(ctx):
+        if ctx.timestep >= 500:
+            idx.step(ctx.noise, 0.5)
+    torch.manual_seed(ok_seed)
+    out, inj = run.sample(noise, 3, "ddim", "normal", inject_n_rand=1, step_callback=cb)
+    torch.cuda.synchronize()
+    torch.manual_seed(ok_seed)
+    with torch.no_grad():
+        ref, rinj = ORC.sample_frames(sd, cfg, noise, None, None, ids.numpy(), 3, scale, "ddim", "normal",
+                                      overlap=dict(ratio=0.5, stop=500, n_rand=1), cond_entries=(entries_of(pos), entries_of(neg)))
+    assert inj == [int(i) for i in rinj]
+    err = (out.cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < 2e-3, err
+    torch.manual_seed(bad_seed)                                 # an index the smaller model calls do not have
+    with pytest.raises(IndexError):
+        run.sample(noise, 3, "ddim", "normal", inject_n_rand=1, step_callback=cb)
+    torch.manual_seed(bad_seed)
+    with pytest.raises(IndexError), torch.no_grad():
+        ORC.sample_frames(sd, cfg, noise, None, None, ids.numpy(), 3, scale, "ddim", "normal",
+                          overlap=dict(ratio=0.5, stop=500, n_rand=1), cond_entries=(entries_of(pos), entries_of(neg)))
+
+
+def test_controlnets_with_conditioning_areas_vs_oracle():
+    """ControlNets + conditioning AREAS: the control net of a model call on a crop sees the cropped latent and the WHOLE hint
+    resized to 8x the crop (ControlNet.get_control -> common_upscale(..., 'nearest-exact', 'center'), comfy/controlnet.py:193-201,
+    samplers.py:271-276).  Oracle: the same composition from its pinned pieces (was NotImplementedError until round 3)"""
+    import sr_oracle as ORC
+    from stable_renderer_amd.conditioning import entries_of
+    from stable_renderer_amd.controlnet import ControlNet
+    from stable_renderer_amd.sampling import DiffusionRunner
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    sd_u, sd_c = _sd("unet_tiny_keys.json", 1), _sd("controlnet_tiny_keys.json", 5)
+    N, h, w, steps, scale, strength = 2, 16, 24, 3, 4.0, 0.8
+    g = torch.Generator().manual_seed(31)
+    noise = torch.randn(N, 4, h, w, generator=g)
+    hint = torch.rand(N, 3, 8 * h, 8 * w, generator=g)
+
+    def c(seed):
+        return torch.randn(1, 77, 64, generator=torch.Generator().manual_seed(seed))
+    pos = [[c(4), {}], [c(5), {"area": ("percentage", 0.5, 0.5, 0.25, 0.25), "strength": 0.9}]]
+    neg = [[c(7), {}]]
+    net = UNet(sd_u, cfg, dtype=torch.float32)
+    run = DiffusionRunner(net, N, h, w, scale, n_ctx=77, use_graph=False, controlnets=[ControlNet(sd_c, cfg, dtype=torch.float32, strength=strength)])
+    run.set_cond_entries(entries_of(pos), entries_of(neg))
+    run.set_control_hints([hint])
+    torch.manual_seed(3)
+    out, _ = run.sample(noise, steps, "euler", "normal")
+    torch.cuda.synchronize()
+    assert len(run._general["groups"]) == 2
+
+    ms = ORC.ModelSampling()
+    sig, _ = ORC.ksampler_sigmas(ms, "normal", steps, None)
+    entries = ORC.prepare_cond_entries(entries_of(pos), entries_of(neg), h, w)
+
+    def model_fn(xin, s2, ctx):
+        hh = hint if xin.shape[2:] == (h, w) else ORC.common_upscale_center(hint, xin.shape[3] * 8, xin.shape[2] * 8)
+        hh = torch.cat([hh] * (xin.shape[0] // N))
+        t = ms.timestep(s2).float()
+        xc = ORC.eps_input(xin, s2)
+        ctrl = ORC.controlnet_forward(sd_c, cfg, xc, hh, t, ctx, strength=strength)
+        return ORC.eps_denoised(xin, ORC.unet_forward(sd_u, cfg, xc, t, ctx, control=ctrl), s2)
+    torch.manual_seed(3)
+    x0 = noise * torch.sqrt(1.0 + sig[0] ** 2.0)
+    with torch.no_grad():
+        ref = ORC.sample_loop(lambda xx, sigma: ORC.sampling_function(model_fn, xx, sigma, entries[1], entries[0], scale), x0.clone(), sig,
+                              "euler", None) / 0.18215
+    err = (out.cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    assert err < 2e-3, err

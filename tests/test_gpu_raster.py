@@ -116,6 +116,23 @@ def test_hip_rasterizer_matches_reference_dump(gold, fr):
     check_against_reference_dump(d, fr, cov, out[0].pos.cpu().numpy(), out[0].id[..., 3].cpu().numpy(), out[1].id[..., 3].cpu().numpy())
 
 
+@pytest.mark.parametrize("fr", (8, 31, 50))
+def test_hip_rasterizer_normal_and_depth_planes_match_reference_dump(gold, fr):
+    """the HIP rasterizer's normal + depth plane against the reference's own normal/ and depth/ dumps of the same sphere scene
+    (fixture raster_pin_planes.npz): packed normals within 1/255, reversed min-max-normalised depth, empty noise / canny planes"""
+    from stable_renderer_amd import scene as S
+    from test_raster_pin import check_planes_against_reference_dump
+    d = gold("raster_pin_planes")
+    gb = S.GBuffer(512, 512)
+    gb.clear()
+    t = S.DrawTask(S.Mesh.Sphere(32), d[f"MV_{fr}"], use_texcoord_id=True, id_size=(1024, 0))
+    gb.draw(t, np.eye(4, dtype=np.float32), d["P"])
+    torch.cuda.synchronize()
+    cov = (gb.id[..., 0] != 0).cpu().numpy()
+    check_planes_against_reference_dump(d, fr, cov, gb.normal_depth.float().cpu().numpy())
+    assert not bool(gb.noise.any()) and not bool(gb.canny.any())
+
+
 @pytest.mark.parametrize("frame", (0, 5))
 def test_boatlike_obj_through_mesh_load_bit_exact(frame):
     """BASELINE config 3's geometry path: a Blender-style OBJ (v/vt/vn corners, quads + n-gons to fan-triangulate, relative

@@ -56,3 +56,63 @@ def test_oracle_rasterizer_matches_reference_dump(gold, fr):
     keys = [str(k) for k in d["stat_keys"]]
     st = dict(zip(keys, d[f"stats_{fr}"]))
     assert int(st["cov_oracle"]) == int(cov.sum())          # the oracle is deterministic: the recorded verdict reproduces
+
+
+# ---- the normal and depth planes of the same dumps (fixture tests/golden/raster_pin_planes.npz, oracle/pin_raster.py planes) -----
+PLANE_FRAMES = dict(normal=(50,), depth=(50, 31, 8))
+
+
+def check_planes_against_reference_dump(d, fr, cov, nd):
+    """cov (512,512) bool, nd (512,512,4) fp32 = the normal+depth plane of a rasterisation of the recovered scene of frame fr.
+    Encoded as the reference's dump code does (value * 255 truncated; depth min-max normalised over the frame,
+    diffusionManager.py:196-254) and compared with the PNGs the reference wrote:
+      * normal: n * 0.5 + 0.5 per channel within 1/255 on >= 99.5 % of the covered pixels (the rest: silhouette and pole fan);
+      * depth: reversed window depth (closer = larger): within 4/255 on >= 98 % after the same normalisation -- the plane is fp16
+        (450 steps over this scene's range) and the normalisation takes its minimum from silhouette pixels -- and the ORDER of
+        depths agrees (rank correlation), i.e. depth = 1 - z_window and not z_window."""
+    import pin_raster as PR
+    rs = int(d["row_stride"])
+    rows = np.arange(0, 512, rs)
+    ref_cov = np.unpackbits(d[f"cov_{fr}"])[:512 * 512].reshape(512, 512).astype(bool)
+    sub = ref_cov[rows]
+    both = sub & cov[rows]
+    normal, gray, alpha = PR.encode_planes(nd)
+    out = {}
+    if fr in PLANE_FRAMES["normal"]:
+        ref = np.zeros((len(rows), 512, 3), np.int32)
+        ref[sub] = d[f"normal_{fr}"]
+        dn = np.abs(normal[rows][both].astype(np.int32) - ref[both]).max(-1)
+        out["normal_within1"] = float((dn <= 1).mean())
+        assert out["normal_within1"] >= 0.995, (fr, out)
+        assert (normal[~cov] == 0).all()                             # cleared background: (0, 0, 0), as in the dump
+    if fr in PLANE_FRAMES["depth"]:
+        ref = np.zeros((len(rows), 512), np.int32)
+        ref[sub] = d[f"depth_{fr}"]
+        dd = np.abs(gray[rows][both].astype(np.int32) - ref[both])
+        out["depth_within4"] = float((dd <= 4).mean())
+        assert out["depth_within4"] >= 0.98, (fr, out)
+        a, b = gray[rows][both].astype(np.float64), ref[both].astype(np.float64)
+        ra, rb = np.argsort(np.argsort(a)), np.argsort(np.argsort(b))
+        out["depth_rank_corr"] = float(np.corrcoef(ra, rb)[0, 1])
+        assert out["depth_rank_corr"] > 0.999, (fr, out)
+        ref_alpha = np.unpackbits(d[f"depth_alpha_{fr}"])[:512 * 512].reshape(512, 512).astype(bool)
+        assert (alpha == ref_alpha).mean() > 0.999
+        centre = gray[256, 256]
+        assert centre >= 250                                          # the sphere's nearest point is the brightest: reversed depth
+    return out
+
+
+@pytest.mark.parametrize("fr", sorted({f for fs in PLANE_FRAMES.values() for f in fs}))
+def test_oracle_normal_and_depth_planes_match_reference_dump(gold, fr):
+    import pin_raster as PR
+    import raster_ref as R
+    from stable_renderer_amd import scene as S
+    d = gold("raster_pin_planes")
+    m_uv, _ = PR.sphere_meshes()
+    g = R.GBufferRef(512, 512)
+    g.clear()
+    MV, P = d[f"MV_{fr}"], d["P"]
+    t = S.DrawTask(m_uv, np.eye(4, dtype=np.float32), sprite_id=1, material_id=1, render_mode=0, use_texcoord_id=True, id_size=(PR.TEX, 0))
+    g.draw(t, dict(MV=MV.reshape(-1), MV_IT=S.inverse_transpose(MV).reshape(-1), P=P.reshape(-1), depth_test=1))
+    check_planes_against_reference_dump(d, fr, g.id[..., 0] != 0, g.normal_depth.view(np.float16).astype(np.float32))
+    assert not g.noise.any() and not g.canny.any()        # no noise texture -> zeros (frag:102-103); no 80-degree normals in view
