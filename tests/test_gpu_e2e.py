@@ -392,7 +392,7 @@ def test_kv_injection_with_several_model_calls_vs_oracle():
     cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
     sd = _sd("unet_tiny_keys.json", 1)
     net = UNet(sd, cfg, dtype=torch.float32)
-    N, h, w = 2, 16, 24
+    N, h, w = 2, 16, 16                                   # (square: the overlap's x/H, y/W index rule needs it, corresponder.py:321-330)
     pos, neg, scale = _cond_lists(64, h * 8, w * 8)["areas"]
     g = torch.Generator().manual_seed(21)
     noise = torch.randn(N, 4, h, w, generator=g)

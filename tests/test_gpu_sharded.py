@@ -65,10 +65,6 @@ def _run_ranks(target, world, port, timeout=400):
     return [res[r] for r in range(world)]
 
 
-def _worker(rank, world, port, q):
-    _guarded(_worker_body, rank, world, port, q)
-
-
 def _worker_body(rank, world):
     if True:
         from stable_renderer_amd import synth
@@ -118,15 +114,26 @@ def _worker_body(rank, world):
         return (rank, err, inj0, inj1)
 
 
-def test_two_rank_view_shard_matches_single_process():
-    res = _run_ranks(_worker, 2, 29700 + (os.getpid() % 1000))
+def _all_worker(rank, world, port, q):
+    _guarded(_all_body, rank, world, port, q)
+
+
+def _all_body(rank, world):
+    """the three 2-rank scenarios in ONE pair of processes (spawn + torch import + HIP init + library load cost ~15 s per rank and
+    scenario otherwise: a third of the GPU suite's wall time)"""
+    return dict(sample=_worker_body(rank, world), pipe=_pipe_body(rank, world), cn=_cn_body(rank, world))
+
+
+@pytest.fixture(scope="module")
+def two_ranks():
+    return _run_ranks(_all_worker, 2, 29700 + (os.getpid() % 1000), timeout=900)
+
+
+def test_two_rank_view_shard_matches_single_process(two_ranks):
+    res = [r["sample"] for r in two_ranks]
     for rank, err, inj0, inj1 in res:
         assert inj0 == inj1, (inj0, inj1)
         assert err < 1e-4, (rank, err)
-
-
-def _pipe_worker(rank, world, port, q):
-    _guarded(_pipe_body, rank, world, port, q)
 
 
 def _pipe_body(rank, world):
@@ -157,17 +164,13 @@ def _pipe_body(rank, world):
         return (rank, err, same)
 
 
-def test_two_rank_pipeline_shard_bakes_the_same_corrmap():
+def test_two_rank_pipeline_shard_bakes_the_same_corrmap(two_ranks):
     """raster (own views) -> id all-gather -> sharded sampling -> decode -> frames to rank 0 -> ordered corr-map update"""
-    res = _run_ranks(_pipe_worker, 2, 28700 + (os.getpid() % 1000))
+    res = [r["pipe"] for r in two_ranks]
     for rank, err, same in res:
         assert err < 2e-4, (rank, err)
         if rank == 0:
             assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same      # fp16 store of fp32 frames that differ by GEMM batch shape
-
-
-def _cn_worker(rank, world, port, q):
-    _guarded(_cn_body, rank, world, port, q)
 
 
 def _cn_body(rank, world):
@@ -206,8 +209,8 @@ def _cn_body(rank, world):
     return (rank, err, err_g, moved, same)
 
 
-def test_two_ranks_three_frames_each_with_two_controlnets_match_single_process():
-    res = _run_ranks(_cn_worker, 2, 27700 + (os.getpid() % 1000), timeout=600)
+def test_two_ranks_three_frames_each_with_two_controlnets_match_single_process(two_ranks):
+    res = [r["cn"] for r in two_ranks]
     for rank, err, err_g, moved, same in res:
         assert err < 2e-4, (rank, err)
         assert err_g < 1e-5, (rank, err_g)
