@@ -191,6 +191,31 @@ int sr_graph_launch(void* graph_exec, void* stream);
 int sr_graph_destroy(void* graph_exec);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Operator-level entry points: what the reference's model calls look like to a host written in any language.
+ *   sr_unet_forward  replaces  BaseModel.apply_model -> self.diffusion_model(xc, t, context=...)   (comfy/model_base.py:93-127,
+ *                              UNetModel.forward, comfy/ldm/modules/diffusionmodules/openaimodel.py:841-946)
+ *   sr_vae_decode    replaces  VAE.decode -> self.first_stage_model.decode(samples)                  (comfy/sd.py:329-346,
+ *                              Decoder.forward, comfy/ldm/modules/diffusionmodules/model.py:541-650)
+ * A *model bundle* file holds a lowered launch plan in relocatable form -- the sr_op arrays, (tensor, offset) in place of every
+ * device pointer, the tensors' sizes and initial contents (packed weights), the named input / output windows -- for ONE
+ * (weights, batch, resolution, injected-frame count); stable-renderer_amd/bundle.py writes it from a built plan (tiles already chosen by the
+ * tuner).  sr_model_load allocates and uploads on the CURRENT device; the handle is then independent of Python and of torch.
+ * Plans: "prologue" (prompt-only work: cross-attention K / V, label_emb; run when ctx changes) and "step" (one evaluation).
+ * Inputs / outputs by name: UNet "x" (B,4,h,w) fp32, "t" (B,) fp32, "ctx" (B,n_ctx,ctx_dim) in the model dtype, optional "y",
+ * "inject" (n_rand int32 batch indices of the K/V-injected frames), "out" (B,4,h,w) fp32; VAE "z" (N,4,h,w) fp32, "img" (N,H,W,3) fp32.
+ * sr_model_write / sr_model_read / sr_unet_forward / sr_vae_decode accept host OR device pointers (hipMemcpyDefault). */
+typedef struct sr_model sr_model;
+int sr_model_load(const char* path, sr_model** model);
+int sr_model_free(sr_model* model);
+int sr_model_io(sr_model* model, const char* name, void** dev_ptr, int64_t* nbytes);
+int sr_model_run(sr_model* model, const char* plan, void* stream);
+int sr_model_write(sr_model* model, const char* name, const void* src, void* stream);          /* asynchronous on `stream` */
+int sr_model_read(sr_model* model, const char* name, void* dst, void* stream);                 /* synchronises `stream`    */
+/* ctx == NULL: keep the prompt of the previous call (its K / V stay projected).  `out` is complete when `stream` has drained. */
+int sr_unet_forward(sr_model* unet, const float* x, const float* t, const void* ctx, float* out, void* stream);
+int sr_vae_decode(sr_model* vae, const float* z, float* img, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Sampler arithmetic (comfy/model_sampling.py:7-29 EPS; comfy/samplers.py:323-358 CFG;
  * comfy/k_diffusion/sampling.py:129-149 euler, :749-776 ddpm, :779-793 lcm).  All fp32, x is (N,4,h,w). */
 /* xin[0:N] = xin[N:2N] = x / sqrt(sigma^2+1)  (uncond chunk first, then cond; `copies` = 1 or 2) */

@@ -93,6 +93,14 @@ SYMBOLS = {
     "sr_version": (C.c_int, []),
     "sr_source_hash": (C.c_char_p, []),
     "sr_device_sync": (C.c_int, []),
+    "sr_model_load": (C.c_int, [C.c_char_p, P(vp)]),
+    "sr_model_free": (C.c_int, [vp]),
+    "sr_model_io": (C.c_int, [vp, C.c_char_p, P(vp), P(i64)]),
+    "sr_model_run": (C.c_int, [vp, C.c_char_p, vp]),
+    "sr_model_write": (C.c_int, [vp, C.c_char_p, vp, vp]),
+    "sr_model_read": (C.c_int, [vp, C.c_char_p, vp, vp]),
+    "sr_unet_forward": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+    "sr_vae_decode": (C.c_int, [vp, vp, vp, vp]),
     "sr_igemm": (C.c_int, [P(IgemmArgs), vp]),
     "sr_groupnorm": (C.c_int, [P(GroupNormArgs), vp]),
     "sr_groupnorm_scratch_floats": (i64, [i32, i32]),

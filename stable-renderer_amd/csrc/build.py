@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libsr_hip.so")
-SOURCES = ["errors.cpp", "hostutil.cpp", "igemm.hip", "norm.hip", "attention.hip", "eltwise.hip", "overlap.hip", "plan.hip", "raster.hip"]
+SOURCES = ["errors.cpp", "hostutil.cpp", "model.cpp", "igemm.hip", "norm.hip", "attention.hip", "eltwise.hip", "overlap.hip", "plan.hip", "raster.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # the rasterizer's fp32 evaluation order is its specification (bit parity with oracle/raster_ref.c): no FMA contraction
 EXTRA = {"raster.hip": ["-ffp-contract=off"],

@@ -1,0 +1,186 @@
+// Operator-level entry points of the C ABI (include/sr_hip.h: sr_model_*, sr_unet_forward, sr_vae_decode).
+//
+// A *model bundle* is a launch plan made relocatable: the flat sr_op arrays a Python host lowered a UNet / VAE to (unet.py,
+// vae.py, plan.py -- once per (weights, batch, resolution), tiles already chosen by the tuner), every device pointer in them
+// replaced by (tensor id, byte offset), plus the tensor table (size, initial contents: packed weights, norm parameters, zero
+// pages; activations are zero-filled) and the named input / output windows.  sr_model_load allocates the tensors on the current
+// device, uploads their contents and patches the pointers back in; from then on a host written in any language runs
+//     sr_unet_forward(m, x, t, ctx, out, stream)          = UNetModel.forward       (openaimodel.py:841-946)
+//     sr_vae_decode(m, z, img, stream)                    = VAE.decode              (comfy/sd.py:329-346)
+// through this library alone -- no Python, no torch in the process (tests/test_gpu_model_bundle.py does exactly that from a
+// child process that imports neither).  The file is produced by stable-renderer_amd/bundle.py:export_bundle.
+//
+// File layout (little endian):  "SRMODEL1" | u32 version=1 | u32 n_tensors | u32 n_io | u32 n_plans
+//   tensors[n_tensors] : u64 nbytes, u64 data_offset (0 = zero-filled, else absolute file offset of nbytes bytes)
+//   io[n_io]           : char name[32], u32 tensor, u32 is_output, u64 offset, u64 nbytes
+//   plans[n_plans]     : char name[16], u32 n_ops, u32 n_reloc, u32 sizeof_op, u32 pad,
+//                        ops[n_ops * sizeof_op], reloc[n_reloc] = { u32 op, u32 field_offset, u32 tensor, u32 pad, u64 offset }
+#include "sr_common.h"
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+struct Io { char name[32]; uint32_t tensor, is_output; uint64_t offset, nbytes; };
+struct Reloc { uint32_t op, field, tensor, pad; uint64_t offset; };
+struct PlanRec { char name[16]; std::vector<sr_op> ops; };
+}  // namespace
+
+struct sr_model {
+  std::vector<void*> tensors;
+  std::vector<uint64_t> sizes;
+  std::vector<Io> io;
+  std::vector<PlanRec> plans;
+  int device = -1;
+};
+
+static bool rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
+
+static void free_model(sr_model* m) {
+  if (!m) return;
+  for (void* p : m->tensors) if (p) (void)hipFree(p);
+  delete m;
+}
+
+extern "C" int sr_model_load(const char* path, sr_model** out) {
+  if (!path || !out) SR_FAIL(SR_ERR_INVALID, "sr_model_load: null argument");
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) SR_FAIL(SR_ERR_INVALID, "sr_model_load: cannot open %s", path);
+  char magic[8];
+  uint32_t hdr[4];
+  if (!rd(f, magic, 8) || memcmp(magic, "SRMODEL1", 8) != 0 || !rd(f, hdr, sizeof(hdr)) || hdr[0] != 1) {
+    fclose(f);
+    SR_FAIL(SR_ERR_INVALID, "sr_model_load: %s is not a version-1 model bundle", path);
+  }
+  const uint32_t nt = hdr[1], nio = hdr[2], np = hdr[3];
+  sr_model* m = new sr_model();
+  (void)hipGetDevice(&m->device);
+  std::vector<uint64_t> data_off(nt);
+  m->sizes.resize(nt);
+  m->tensors.assign(nt, nullptr);
+  bool ok = true;
+  for (uint32_t i = 0; i < nt && ok; ++i) { uint64_t v[2]; ok = rd(f, v, sizeof(v)); m->sizes[i] = v[0]; data_off[i] = v[1]; }
+  m->io.resize(nio);
+  for (uint32_t i = 0; i < nio && ok; ++i) ok = rd(f, &m->io[i], sizeof(Io));
+  std::vector<std::vector<Reloc>> relocs(np);
+  m->plans.resize(np);
+  for (uint32_t i = 0; i < np && ok; ++i) {
+    uint32_t ph[4];
+    ok = rd(f, m->plans[i].name, 16) && rd(f, ph, sizeof(ph));
+    if (ok && ph[2] != sizeof(sr_op)) {
+      fclose(f); free_model(m);
+      SR_FAIL(SR_ERR_INVALID, "sr_model_load: bundle built for sizeof(sr_op) = %u, this library has %zu (re-export it)", ph[2], sizeof(sr_op));
+    }
+    if (!ok) break;
+    m->plans[i].ops.resize(ph[0]);
+    relocs[i].resize(ph[1]);
+    ok = (ph[0] == 0 || rd(f, m->plans[i].ops.data(), (size_t)ph[0] * sizeof(sr_op))) && (ph[1] == 0 || rd(f, relocs[i].data(), (size_t)ph[1] * sizeof(Reloc)));
+  }
+  if (!ok) { fclose(f); free_model(m); SR_FAIL(SR_ERR_INVALID, "sr_model_load: %s is truncated", path); }
+  // ---- tensors: allocate, zero or upload
+  std::vector<char> stage;
+  for (uint32_t i = 0; i < nt; ++i) {
+    const uint64_t nb = m->sizes[i] ? m->sizes[i] : 16;
+    if (hipMalloc(&m->tensors[i], nb) != hipSuccess) { fclose(f); free_model(m); SR_FAIL(SR_ERR_LAUNCH, "sr_model_load: hipMalloc of %llu bytes failed", (unsigned long long)nb); }
+    if (data_off[i] == 0) {
+      if (hipMemset(m->tensors[i], 0, nb) != hipSuccess) { fclose(f); free_model(m); SR_FAIL(SR_ERR_LAUNCH, "sr_model_load: hipMemset failed"); }
+    } else {
+      stage.resize(m->sizes[i]);
+      if (fseek(f, (long)data_off[i], SEEK_SET) != 0 || !rd(f, stage.data(), m->sizes[i]) ||
+          hipMemcpy(m->tensors[i], stage.data(), m->sizes[i], hipMemcpyHostToDevice) != hipSuccess) {
+        fclose(f); free_model(m);
+        SR_FAIL(SR_ERR_INVALID, "sr_model_load: cannot read / upload tensor %u of %s", i, path);
+      }
+    }
+  }
+  fclose(f);
+  // ---- relocations: (tensor, offset) -> device pointer, written into the pointer field of the op
+  for (uint32_t i = 0; i < np; ++i)
+    for (const Reloc& r : relocs[i]) {
+      if (r.op >= m->plans[i].ops.size() || r.tensor >= nt || r.field + sizeof(void*) > sizeof(sr_op) || r.offset > m->sizes[r.tensor]) {
+        free_model(m);
+        SR_FAIL(SR_ERR_INVALID, "sr_model_load: bad relocation in plan %u", i);
+      }
+      char* field = (char*)&m->plans[i].ops[r.op] + r.field;
+      void* ptr = (char*)m->tensors[r.tensor] + r.offset;
+      memcpy(field, &ptr, sizeof(void*));
+    }
+  for (const Io& e : m->io)
+    if (e.tensor >= nt || e.offset + e.nbytes > m->sizes[e.tensor]) { free_model(m); SR_FAIL(SR_ERR_INVALID, "sr_model_load: bad io window"); }
+  *out = m;
+  return SR_OK;
+}
+
+extern "C" int sr_model_free(sr_model* m) {
+  free_model(m);
+  return SR_OK;
+}
+
+static const Io* find_io(const sr_model* m, const char* name) {
+  for (const Io& e : m->io)
+    if (strncmp(e.name, name, sizeof(e.name)) == 0) return &e;
+  return nullptr;
+}
+
+extern "C" int sr_model_io(sr_model* m, const char* name, void** dev_ptr, int64_t* nbytes) {
+  if (!m || !name) SR_FAIL(SR_ERR_INVALID, "sr_model_io: null argument");
+  const Io* e = find_io(m, name);
+  if (!e) SR_FAIL(SR_ERR_INVALID, "sr_model_io: the bundle has no input / output named '%s'", name);
+  if (dev_ptr) *dev_ptr = (char*)m->tensors[e->tensor] + e->offset;
+  if (nbytes) *nbytes = (int64_t)e->nbytes;
+  return SR_OK;
+}
+
+extern "C" int sr_model_run(sr_model* m, const char* plan, void* stream) {
+  if (!m || !plan) SR_FAIL(SR_ERR_INVALID, "sr_model_run: null argument");
+  for (const PlanRec& p : m->plans)
+    if (strncmp(p.name, plan, sizeof(p.name)) == 0) return sr_plan_run(p.ops.data(), (int32_t)p.ops.size(), stream);
+  SR_FAIL(SR_ERR_INVALID, "sr_model_run: the bundle has no plan named '%s'", plan);
+}
+
+// src / dst may be host or device memory (hipMemcpyDefault resolves it): a host without any HIP binding feeds host buffers
+static int io_copy(sr_model* m, const char* name, const void* src, void* dst, bool write, void* stream, const char* who) {
+  const Io* e = find_io(m, name);
+  if (!e) SR_FAIL(SR_ERR_INVALID, "%s: the bundle has no input / output named '%s'", who, name);
+  void* dev = (char*)m->tensors[e->tensor] + e->offset;
+  const hipError_t rc = write ? hipMemcpyAsync(dev, src, e->nbytes, hipMemcpyDefault, sr_stream(stream))
+                              : hipMemcpyAsync(dst, dev, e->nbytes, hipMemcpyDefault, sr_stream(stream));
+  if (rc != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "%s: copy of '%s' failed: %s", who, name, hipGetErrorString(rc));
+  return SR_OK;
+}
+
+extern "C" int sr_model_write(sr_model* m, const char* name, const void* src, void* stream) {
+  if (!m || !name || !src) SR_FAIL(SR_ERR_INVALID, "sr_model_write: null argument");
+  return io_copy(m, name, src, nullptr, true, stream, "sr_model_write");
+}
+
+extern "C" int sr_model_read(sr_model* m, const char* name, void* dst, void* stream) {
+  if (!m || !name || !dst) SR_FAIL(SR_ERR_INVALID, "sr_model_read: null argument");
+  const int rc = io_copy(m, name, nullptr, dst, false, stream, "sr_model_read");
+  if (rc != SR_OK) return rc;
+  if (hipStreamSynchronize(sr_stream(stream)) != hipSuccess) SR_FAIL(SR_ERR_LAUNCH, "sr_model_read: stream synchronisation failed");
+  return SR_OK;
+}
+
+extern "C" int sr_unet_forward(sr_model* m, const float* x, const float* t, const void* ctx, float* out, void* stream) {
+  if (!m || !x || !t || !out) SR_FAIL(SR_ERR_INVALID, "sr_unet_forward: null argument");
+  int rc;
+  if (ctx) {                                                 // a new prompt: cross-attention K / V are projected once (prologue plan)
+    if ((rc = io_copy(m, "ctx", ctx, nullptr, true, stream, "sr_unet_forward")) != SR_OK) return rc;
+    if ((rc = sr_model_run(m, "prologue", stream)) != SR_OK) return rc;
+  }
+  if ((rc = io_copy(m, "x", x, nullptr, true, stream, "sr_unet_forward")) != SR_OK) return rc;
+  if ((rc = io_copy(m, "t", t, nullptr, true, stream, "sr_unet_forward")) != SR_OK) return rc;
+  if ((rc = sr_model_run(m, "step", stream)) != SR_OK) return rc;
+  return io_copy(m, "out", nullptr, out, false, stream, "sr_unet_forward");
+}
+
+extern "C" int sr_vae_decode(sr_model* m, const float* z, float* img, void* stream) {
+  if (!m || !z || !img) SR_FAIL(SR_ERR_INVALID, "sr_vae_decode: null argument");
+  int rc;
+  if ((rc = io_copy(m, "z", z, nullptr, true, stream, "sr_vae_decode")) != SR_OK) return rc;
+  if ((rc = sr_model_run(m, "step", stream)) != SR_OK) return rc;
+  return io_copy(m, "img", nullptr, img, false, stream, "sr_vae_decode");
+}
