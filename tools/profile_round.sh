@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round profile (development tool; run on the GPU box from the repo root: `bash tools/profile_round.sh r02`).
+# Round profile (development tool; run on the GPU box from the repo root: `bash tools/profile_round.sh r03`).
 #   1. tile-tuner table written once (un-profiled) so the profiled runs make no tuning launches
 #   2. rocprofv3 --kernel-trace --stats of the bench command and of `bench.py --roofline-only`
 #   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE; separate: together they exceed the TCC slots) of `bench.py --roofline-only`
 #      -> HBM-side bytes of the igemm family per UNet evaluation (tools/summarize_traffic.py)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
