@@ -489,20 +489,27 @@ class DiffusionRunner:
                     t_inj = torch.tensor(inject, dtype=torch.int64)
                     PAR.broadcast(t_inj, 0, self.shard.group)
                     inject = t_inj.tolist()
+            # ddpm / lcm draw one noise tensor per step from the global generator (default_noise_sampler).  With calls in flight
+            # (rng_turn) those draws would interleave with other calls' draws: take them all here, inside this call's turn, in
+            # the order the loop below would have made them -- the generator then sees exactly the sequential loop's sequence
+            predrawn = None
+            if rng_turn is not None and noise_fn is None and sampler in ("ddpm", "lcm"):
+                predrawn = [torch.randn(tuple(self.x.shape), dtype=torch.float32) for i in range(len(sig) - 1) if float(sig[i + 1]) > 0]
         latent = torch.zeros_like(noise) if latent_image is None else latent_image * self.latent_scale
         max_denoise = math.isclose(float(self.ms.sigma_max), float(sig[0]), rel_tol=1e-05) or float(sig[0]) > float(self.ms.sigma_max)
         s0 = float(torch.sqrt(1.0 + sig[0] ** 2.0)) if max_denoise else float(sig[0])
         self.x.copy_(noise.to(dev, torch.float32))
         O.axpby(self.x, latent.to(dev, torch.float32).contiguous(), 1.0, s0)        # x = noise*s0 + latent
-        if rng_turn is not None and sampler in ("ddpm", "lcm"):
-            raise NotImplementedError("calls in flight draw per-step noise from the global generator with ddpm / lcm")
         if general:
             self._general_plans(inject)
             p = G["groups"][0]["plan"]
         else:
             p = self._ensure_plan(inject)
             self._load_ctx(p)
-        if noise_fn is None:
+        if noise_fn is None and predrawn is not None:
+            def noise_fn():
+                return predrawn.pop(0).to(dev)
+        elif noise_fn is None:
             def noise_fn():
                 return torch.randn(tuple(self.x.shape), dtype=torch.float32).to(dev)    # default_noise_sampler (CPU x)
         t_index = [int(t) for t in self.ms.timestep(sig[:-1])]          # ModelSamplingDiscrete.timestep, once per run

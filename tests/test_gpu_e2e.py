@@ -265,6 +265,32 @@ def test_calls_in_flight_equal_the_sequential_loop(monkeypatch):
     assert torch.equal(w1, w3) and same(v1, v3) and torch.equal(r1, r3)
 
 
+def test_calls_in_flight_with_a_sampler_that_draws_noise_every_step(monkeypatch):
+    """ddpm draws one noise tensor per step from the global generator: with calls in flight the draws of a call are taken inside
+    its RNG turn, so the generator sees the sequential loop's sequence (was NotImplementedError until round 3)"""
+    from stable_renderer_amd.pipeline import build_sd15_pipeline, InflightCalls
+    from stable_renderer_amd.unet import SD15_CFG
+    monkeypatch.setenv("SR_AUTOTUNE", "0")
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    kw = dict(dtype=torch.float32, n_views=2, steps=3, cfg=5.0, W=128, H=128, unet_cfg=cfg, vae_ch=32)
+
+    def bake(inflight):
+        pipe = build_sd15_pipeline(**kw)
+        pipe.sampler = "ddpm"
+        torch.manual_seed(78)
+        if inflight == 1:
+            for _ in range(4):
+                pipe.call()
+        else:
+            InflightCalls(pipe, inflight).run(4)
+        torch.cuda.synchronize()
+        cm = pipe.scene.corrmap
+        return cm._values.clone(), cm._writtens.clone(), torch.get_rng_state()
+    v1, w1, r1 = bake(1)
+    v2, w2, r2 = bake(2)
+    assert int(w1.sum()) > 0 and torch.equal(w1, w2) and torch.equal(v1, v2) and torch.equal(r1, r2)
+
+
 def test_sampling_with_an_sdxl_family_unet_needs_and_uses_vector_conditioning():
     """DiffusionRunner over the SDXL-family lowering (label_emb): y is required, reaches both CFG halves, changes the result"""
     from stable_renderer_amd import synth
