@@ -82,9 +82,7 @@ typedef struct {
                              images: the activation halo is staged once per 32-channel chunk and the nine taps read it at nine LDS
                              offsets; SR_ERR_INVALID otherwise), 9 = 128x160 and 10 = 128x320 with 64-byte K-steps (fp16; two co-resident
                              workgroups per CU for the K-short linear layers), 11 = 128x128 as 8 waves and 12 = 256x128 with 64-byte K-steps
-                             (fp16; the same for widths that are multiples of 128 only), 13 = X-stationary GEGLU (fp16, act 2, 1x1, 128 <= K <= 320, N % 320 == 0,
-                             M % 128 == 0: the activation tile stays in LDS, W streams past it; experimental, not offered by the tuner).
-                             Set by the host-side per-shape tuner (ops.tune_igemm)  */
+                             (fp16; the same for widths that are multiples of 128 only).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
   int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split, 2..16 = split the
                              partly empty last round of workgroups this many ways over K (tiles 2 / 3; what the
                              per-shape tuner measures)                                                          */

@@ -255,41 +255,6 @@ def test_igemm_folded_layernorm(ops, dtype, mode):
     close(got, ref, dtype, scale=ref.abs().max().item())
 
 
-@pytest.mark.parametrize("K,N,M,fold", [(320, 2560, 1024, False), (320, 2560, 640, True), (320, 320, 256, False), (128, 640, 384, True), (192, 960, 128, False)])
-def test_igemm_x_stationary_geglu(ops, K, N, M, fold):
-    """tile 13: the activation tile stays in LDS, all of W streams past it (K-short GEGLU projections, ff.net.0): against torch,
-    with bias and with the folded-LayerNorm terms, and against the tile kernels' result for the same layer"""
-    dtype, dev = torch.float16, "cuda"
-    x = rnd(1, M, K) * 1.3 + 0.2
-    w = rnd(2, N, K) * K ** -0.5
-    bias = rnd(3, N) * 0.1
-    xd, wd = x.to(dtype), w.to(dtype)
-    if fold:
-        gamma, beta = 1 + 0.1 * rnd(4, K), 0.1 * rnd(5, K)
-        ln = F.layer_norm(xd.float(), (K,), gamma, beta, 1e-5)
-        ref = ln @ w.t() + bias
-        wp, cs, b2 = ops.fold_layernorm(w, bias, gamma, beta, dtype, geglu=True)
-        st = ops.row_stats(xd.to(dev))
-        kw = dict(bias=b2.to(dev), row_stats=st, colsum=cs.to(dev))
-        wp = wp.to(dev)
-    else:
-        ref = xd.float() @ wd.float().t() + bias
-        wp = ops.pack_conv_weight(w, dtype, geglu=True).to(dev)
-        kw = dict(bias=ops.pack_bias(bias, geglu=True).to(dev))
-    a, g = ref.chunk(2, dim=1)
-    ref = a * F.gelu(g)
-    outs = []
-    for tile in (13, 0):
-        out = torch.full((M, N // 2), 7.0, dtype=dtype, device=dev)
-        ops.igemm(xd.to(dev), wp, out, M, 1, 1, K, N, act=2, tile=tile, split=-1, **kw)
-        torch.cuda.synchronize()
-        outs.append(out.float().cpu())
-    close(outs[0], ref, dtype, scale=ref.abs().max().item() * (3.0 if fold else 1.0))
-    assert (outs[0] - outs[1]).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())     # same arithmetic, other tile
-    with pytest.raises(Exception):                              # shapes the kernel is not built for are refused, not mis-run
-        ops.igemm(xd.to(dev), wp, torch.empty(M, N // 2, dtype=dtype, device=dev), M, 1, 1, K, N, act=0, tile=13, split=-1)
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_out_f32_and_scale(ops, dtype):
     ke = ops.kelems(dtype)
