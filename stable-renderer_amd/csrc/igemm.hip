@@ -958,7 +958,6 @@ static int launch_conv3p(const sr_igemm_args& a, int M, hipStream_t st) {
   return SR_OK;
 }
 
-
 // Wave quantisation model for the 4-wave tiles (calibrated on MI355X): `slots` workgroups are co-resident
 // chip-wide, a round of co-resident workgroups takes t_k microseconds per K-step, partials cost their HBM round trip.
 // Returns the split count for the tail round (1 = none) and sets tile0 (tiles before it run unsplit).
