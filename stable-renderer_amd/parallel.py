@@ -149,12 +149,15 @@ class ViewShard:
         dist.gather(frames_local, out, dst=0, group=self.group)
         return torch.cat(out, 0).to(dev) if self.rank == 0 else None
 
-    def owner_of(self, global_batch_index):
-        """global batch entry of calc_cond_uncond_batch's [uncond views | cond views] order -> (owner rank, index in that
-        rank's local batch [uncond local | cond local])"""
+    def owner_of(self, global_batch_index, chunks=None):
+        """global batch entry of a model call -- calc_cond_uncond_batch lays its chunks out one after the other, every chunk
+        holding all views: [uncond views | cond views] in the plain case, `chunks` of them for conditioning lists -> (owner
+        rank, index in that rank's local batch, which has the same chunk order over its own views)"""
         g = int(global_batch_index)
-        cond, view = g >= self.n_views, g % self.n_views
-        return view // self.n_local, (self.n_local if cond else 0) + view % self.n_local
+        chunk, view = g // self.n_views, g % self.n_views
+        if chunks is not None and chunk >= chunks:
+            raise IndexError(f"batch entry {g} outside a model call of {chunks} x {self.n_views} entries")
+        return view // self.n_local, chunk * self.n_local + view % self.n_local
 
 
 def timed_max_over_ranks(seconds, device):

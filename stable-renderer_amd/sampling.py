@@ -250,8 +250,6 @@ class DiffusionRunner:
         if CD.is_plain(positive) and CD.is_plain(negative):
             self._entries = None
             return self.set_conditioning(positive[0]["cond"], negative[0]["cond"])
-        if self.shard is not None and self.shard.active:
-            raise NotImplementedError("mask / area conditioning lists inside a view-sharded group")
         self._entries = (list(positive), list(negative))
         self._general = None
 
@@ -261,6 +259,19 @@ class DiffusionRunner:
         N, h, w = self.N, self.h, self.w
         C = self.unet.cfg["in_channels"]
         pos, neg = CD.prepare(self._entries[0], self._entries[1], h, w)
+        sharded = self.shard is not None and self.shard.active
+        if sharded:
+            # a mask batch that follows the views of the WHOLE group (one mask per view) is cut to this rank's views; a single
+            # mask serves every view as it does unsharded (get_area_and_mult repeats the mask batch over the latent batch)
+            def own_views(e):
+                m = e.get("mask")
+                if m is not None and m.shape[0] == self.shard.n_views and self.shard.n_views != N:
+                    e = dict(e)
+                    e["mask"] = m[self.shard.slice]
+                elif m is not None and m.shape[0] not in (1, N):
+                    raise ValueError(f"a mask batch of {m.shape[0]} fits neither the group ({self.shard.n_views} views) nor this rank ({N})")
+                return e
+            pos, neg = [own_views(e) for e in pos], [own_views(e) for e in neg]
         groups = CD.groups_of(pos, neg, N, C, h, w, use_uncond=self.copies == 2)
         dev = self.x.device
         for g in groups:
@@ -278,6 +289,7 @@ class DiffusionRunner:
     def _general_plans(self, inject):
         """build (once per injected-frame COUNT) and load the plans of the general path"""
         G = self._general
+        sharded = self.shard is not None and self.shard.active
         key = None if inject is None else len(inject)
         if G["built_for"] != ("built", key):
             for g in G["groups"]:
@@ -286,16 +298,19 @@ class DiffusionRunner:
                 control, inputs, cn = None, None, None
                 if self.controlnets:
                     control, inputs, cn = self._build_controls(B, ah, aw, g["n_ctx"])
-                g["plan"] = self.unet.build(B, ah, aw, inject_idx=inject, n_ctx=g["n_ctx"], control=control, inputs=inputs)
+                g["plan"] = self.unet.build(B, ah, aw, inject_idx=inject, n_ctx=g["n_ctx"], control=control, inputs=inputs,
+                                            inject_external=sharded and inject is not None)
                 g["plan"]["cn"] = cn
             G["built_for"] = ("built", key)
+        self._inject_global = inject
         for g in G["groups"]:
             p, N = g["plan"], self.N
             if inject is not None:
-                B = N * g["chunks"]
+                B = (self.shard.n_views if sharded else N) * g["chunks"]      # the indices address the WHOLE group's batch of this call
                 if any(int(i) < 0 or int(i) >= B for i in inject):
                     raise IndexError(f"injected frame index out of range: {list(inject)}")
-                p["inject"].copy_(torch.tensor([int(i) for i in inject], dtype=torch.int32))
+                if not sharded:
+                    p["inject"].copy_(torch.tensor([int(i) for i in inject], dtype=torch.int32))
             dt = p["ctx"].dtype
             for j, (_, e, _) in enumerate(g["members"]):
                 p["ctx"][j * N:(j + 1) * N].copy_(e["cond"].to(p["ctx"].device).to(dt).expand(N, -1, -1))
@@ -340,7 +355,10 @@ class DiffusionRunner:
                 for cp in p["cn"]["plans"]:
                     cp["step"].run()
                 p["cn"]["merge"].run()
-            p["step"].run()
+            if p["schedule"]:                                # view-sharded group: segments + K/V-source broadcasts
+                self._sharded_eval(p, chunks=g["chunks"])
+            else:
+                p["step"].run()
             O.cond_accumulate(self.x, p["out"], g["mult"], g["kinds"], G["out_c"], G["cnt_c"], G["out_u"], G["cnt_u"], g["area"],
                               g["chunks"], sigma)
         O.cfg_combine(self.x, G["out_c"], G["cnt_c"], G["out_u"], G["cnt_u"], self.den, self.d if want_d else None, sigma,
@@ -399,7 +417,7 @@ class DiffusionRunner:
             p["step"].run()
         return p["out"]
 
-    def _sharded_eval(self, p):
+    def _sharded_eval(self, p, chunks=None):
         """view-sharded group: the injected frame's post-LayerNorm tokens live on ONE rank.  The step plan is cut twice per
         transformer block (BlockLowering.schedule): after norm1 the owner's rows go out over xGMI as an asynchronous RCCL
         broadcast while every rank computes its own Q projection; the compute stream only waits for the rows before the K / V
@@ -407,12 +425,13 @@ class DiffusionRunner:
         ``time_comm``) accumulates the time the compute stream spent stalled in those waits = the EXPOSED communication."""
         from . import parallel as PAR
         sched = p["schedule"]
-        if self.use_graph and not self._captured:
+        if self.use_graph and not p.get("_segments_captured"):       # (per plan: conditioning lists run several plans per step)
             torch.cuda.current_stream().synchronize()
             for kind, *rest in sched:                       # all captures up front: none while a collective is in flight
                 if kind == "run" and rest[0].n > 0:
                     rest[0].capture(self._stream)
             self._stream.synchronize()
+            p["_segments_captured"] = True
             self._captured = True
         pending = []
         for kind, *rest in sched:
@@ -421,7 +440,7 @@ class DiffusionRunner:
             elif kind == "bcast":
                 for ln, src in rest[0]:                      # the rows and, with the folded LayerNorm, their statistics
                     for j, g in enumerate(self._inject_global):
-                        owner, li = self.shard.owner_of(g)
+                        owner, li = self.shard.owner_of(g, chunks)
                         if owner == self.shard.rank:
                             src[j].copy_(ln[li])
                         pending.append(PAR.broadcast_start(src[j], owner, self.shard.group))

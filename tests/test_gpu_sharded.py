@@ -121,7 +121,66 @@ def _all_worker(rank, world, port, q):
 def _all_body(rank, world):
     """the three 2-rank scenarios in ONE pair of processes (spawn + torch import + HIP init + library load cost ~15 s per rank and
     scenario otherwise: a third of the GPU suite's wall time)"""
-    return dict(sample=_worker_body(rank, world), pipe=_pipe_body(rank, world), cn=_cn_body(rank, world))
+    return dict(sample=_worker_body(rank, world), pipe=_pipe_body(rank, world), cn=_cn_body(rank, world), lists=_lists_body(rank, world))
+
+
+def _lists_body(rank, world):
+    """conditioning LISTS (areas, per-view masks, strengths) inside a view-sharded group with OverlapCorresponder: several model
+    calls per step, each a schedule of segments + K/V-source broadcasts; the per-view mask batch is cut to the rank's views"""
+    from stable_renderer_amd import synth, ops as O
+    from stable_renderer_amd.conditioning import entries_of
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    from stable_renderer_amd.parallel import ViewShard
+    from stable_renderer_amd.sampling import DiffusionRunner
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    torch.cuda.set_device(0)
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    ns, norms = unet_names_shapes(cfg)
+    net = UNet(synth.synth_state_dict(ns, seed=1, norm_names=norms), cfg, dtype=torch.float32)
+    N, h, w = 4, 16, 16
+    g = torch.Generator().manual_seed(9)
+
+    def c(seed):
+        return torch.randn(1, 77, 64, generator=torch.Generator().manual_seed(seed))
+    per_view = (torch.rand(N, h * 8, w * 8, generator=g) > 0.5).float()              # one mask per view of the WHOLE group
+    pos = [[c(1), {"strength": 1.2}], [c(2), {"mask": per_view, "mask_strength": 0.7, "set_area_to_bounds": False}],
+           [c(3), {"area": ("percentage", 0.5, 0.5, 0.25, 0.25), "strength": 0.9}]]
+    neg = [[c(4), {}]]
+    ids = torch.zeros(N, h * 8, w * 8, 4, dtype=torch.int32)
+    ids[..., 0] = 1
+    ids[..., 3] = torch.randint(0, 300, (N, h * 8, w * 8), generator=g, dtype=torch.int32)
+    ids = ids.cuda()
+    noise = torch.randn(N, 4, h, w, generator=g)
+    idx_all = O.OverlapIndex(ids, h, w)
+
+    def run(shard, graph):
+        r = DiffusionRunner(net, N if shard is None else shard.n_local, h, w, 4.0, use_graph=graph, shard=shard)
+        r.set_cond_entries(entries_of(pos), entries_of(neg))
+
+        def cb(ctx):
+            if ctx.timestep < 500:
+                return
+            if shard is None:
+                idx_all.step(ctx.noise, 0.5)
+            else:
+                shard.overlap_step(ctx.noise, lambda full: idx_all.step(full, 0.5))
+        # a seed whose injected index exists in every model call of the step (the smaller calls raise IndexError otherwise, as
+        # the reference does: test_gpu_e2e.py::test_kv_injection_with_several_model_calls_vs_oracle)
+        for seed in range(40):
+            torch.manual_seed(seed)
+            try:
+                return r.sample(noise if shard is None else noise[shard.slice], 3, "ddim", "normal", inject_n_rand=1, step_callback=cb), seed
+            except IndexError:
+                continue
+        raise AssertionError("no seed with a common injected index")
+    (base, inj0), seed0 = run(None, False)
+    sh = ViewShard(N)
+    (mine, inj1), seed1 = run(sh, False)
+    (mine_g, inj2), seed2 = run(sh, True)
+    full = sh.gather_latents(mine)
+    torch.cuda.synchronize()
+    err = (full - base).abs().max().item() / max(1.0, base.abs().max().item())
+    return (rank, err, (mine_g - mine).abs().max().item(), inj0, inj1, inj2, (seed0, seed1, seed2))
 
 
 @pytest.fixture(scope="module")
@@ -266,3 +325,10 @@ def test_sharded_path_runs_through_rccl_in_a_one_rank_group():
     assert err_g < 1e-5, err_g
     assert comm_e is not None and comm_g is not None and comm_e >= 0.0 and comm_g >= 0.0      # asynchronous waits were timed
     assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same
+
+
+def test_two_ranks_conditioning_lists_with_overlap_match_single_process(two_ranks):
+    for rank, err, err_g, inj0, inj1, inj2, seeds in [r["lists"] for r in two_ranks]:
+        assert seeds[0] == seeds[1] == seeds[2] and inj0 == inj1 == inj2, (seeds, inj0, inj1, inj2)
+        assert err < 2e-4, (rank, err)
+        assert err_g < 1e-5, (rank, err_g)
