@@ -153,7 +153,7 @@ def main():
             torch.cuda.synchronize()
     if a.roofline_only:                                       # no calls: just the UNet step plan (as a sampling run builds it)
         a.warmup, a.steps, a.no_cpu_baseline = 0, 0, True
-        pipe.runner._load_ctx(pipe.runner._ensure_plan([3]))
+        pipe.runner._load_ctx(pipe.runner._ensure_plan([min(3, 2 * a.views - 1)]))
     inflight = max(1, a.inflight) if (shard is None and not a.roofline_only) else 1
     if inflight > 1:
         from stable_renderer_amd.pipeline import InflightCalls

@@ -82,10 +82,13 @@ typedef struct {
                              images: the activation halo is staged once per 32-channel chunk and the nine taps read it at nine LDS
                              offsets; SR_ERR_INVALID otherwise), 9 = 128x160 and 10 = 128x320 with 64-byte K-steps (fp16; two co-resident
                              workgroups per CU for the K-short linear layers), 11 = 128x128 as 8 waves and 12 = 256x128 with 64-byte K-steps
-                             (fp16; the same for widths that are multiples of 128 only).  Set by the host-side per-shape tuner (ops.tune_igemm)  */
+                             (fp16; the same for widths that are multiples of 128 only), 13 = 64x64 / 14 = 128x64 / 15 = 128x128 with a
+                             deep LDS ring (8 / 6 / 4 stages, one workgroup per CU: for grids of less than one workgroup per CU -- small
+                             batches, the 16x16 / 8x8 levels -- where nothing else hides the latency of a K-step).  Set by the host-side
+                             per-shape tuner (ops.tune_igemm)                                                                 */
   int32_t split;          /* 0 = split-K decided by the library's cost model, -1 = never split, 2..16 = split the
-                             partly empty last round of workgroups this many ways over K (tiles 2 / 3; what the
-                             per-shape tuner measures)                                                          */
+                             partly empty last round of workgroups this many ways over K (tiles 2 / 3 from 32 K-steps of 128
+                             bytes on, tiles 14 / 15 from 8 on; what the per-shape tuner measures)                 */
   int32_t pad_br;         /* 1: a 3x3 conv pads ONLY the bottom / right border (window of output (y,x) starts at input
                              (y*stride, x*stride)): the VAE encoder's Downsample = F.pad(x, (0,1,0,1)) + conv(stride 2,
                              padding 0) (comfy/ldm/modules/diffusionmodules/model.py:77-95).  0: symmetric KH/2 padding          */
@@ -144,6 +147,9 @@ int sr_timestep_embedding(const float* t, void* y, int32_t B, int32_t dim, int32
                                                     /* util.py:241-261: cat(cos, sin)(t * 10000^(-i/half)) */
 int sr_silu(const void* x, void* y, int64_t n, int32_t dtype, void* stream);
 int sr_cast(const void* x, int32_t src_dtype, void* y, int32_t dst_dtype, int64_t n, void* stream);
+/* tuner aid: read [p, p + bytes) (16-byte aligned) so that it sits in L2 / Infinity Cache like a tensor the previous kernel of a plan
+ * has just produced; no output */
+int sr_cache_touch(const void* p, int64_t bytes, void* stream);
 int sr_softmax_rows(void* x, int32_t rows, int32_t cols, int32_t dtype, void* stream);   /* in place; VAE mid attention */
 /* y[j] = x[sel[j]] for j < nsel, rows of row_bytes bytes (multiple of 16); `sel` is a DEVICE int32 array read at run
  * time, so a captured plan stays valid when the injected frame changes: random_k = k_context[_random_frame_indices]

@@ -112,6 +112,7 @@ SYMBOLS = {
     "sr_timestep_embedding": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "sr_silu": (C.c_int, [vp, vp, i64, i32, vp]),
     "sr_cast": (C.c_int, [vp, i32, vp, i32, i64, vp]),
+    "sr_cache_touch": (C.c_int, [vp, i64, vp]),
     "sr_softmax_rows": (C.c_int, [vp, i32, i32, i32, vp]),
     "sr_gather_rows": (C.c_int, [vp, vp, vp, i32, i32, i64, vp, vp]),
     "sr_add_scaled": (C.c_int, [vp, vp, vp, i64, f32, i32, vp]),

@@ -343,6 +343,15 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
   }
 }
 
+// the drain of a STAGES-deep ring: `y` (wave-uniform, < D - 1) younger stages stay in flight -- s_waitcnt takes an immediate
+template <int PS, int D>
+__device__ __forceinline__ void wait_leaving(int y) {
+#define SR_WL(k) if constexpr (D - 1 > k) { if (y == k) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PS * k) : "memory"); return; } }
+  SR_WL(1) SR_WL(2) SR_WL(3) SR_WL(4) SR_WL(5) SR_WL(6)
+#undef SR_WL
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // BKB = bytes of K per LDS stage: 128 (two MFMA k-substeps, 8 rows x 8 chunks per LDS-DMA instruction) or 64 (one k-substep,
 // 16 rows x 4 chunks) -- the 64-byte form halves a stage so that the 256x320 tile gets a FOUR-deep ring in 144 KB (three
 // K-steps of loads in flight instead of one: that tile is otherwise bound by the exposed load latency of every K-step).
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     // 2-slot kernels; SQ_WAIT_ANY was 49 % of the wave cycles).  asm-issued: 64x64 C320 3x3 conv 146 -> 133 us, big conv
     // 1094 -> 1186 TF/s, 64x64 GEGLU 265 -> 251 us, and every 128-wide tile likewise.
     constexpr int D = STAGES - 1;
-    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 8, "ring depth");
     static_assert(PER_STAGE * (D - 1) < 64, "vmcnt immediate");
     const int nk = kt1 - kt0;                            // (split-K: this workgroup's share of the K-steps)
     SR_TS(1);
@@ -599,9 +608,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
       // the asm-issued LDS-DMA is invisible to hipcc's wait-count pass, so these counted waits are the only ordering:
       // leave the min(D-1, remaining) younger stages in flight
       const int younger = nk - 1 - kt;
-      if (younger >= D - 1)                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (D - 1)) : "memory");
-      else if (D == 3 && younger == 1)     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
-      else                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (younger >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE * (D - 1)) : "memory");
+      else                  wait_leaving<PER_STAGE, D>(younger);
       __builtin_amdgcn_s_barrier();                      // stage kt visible to all; everyone finished step kt-1
       if (kt == 0) SR_TS(2);
       if constexpr (SPREAD == 1) {
@@ -761,14 +769,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sr_igemm_args 
 }
 
 // tiles [0, tile0) full-K (ordinary epilogue), tiles [tile0, ntiles) split S ways over K + reduce
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int STAGES = 2>
 int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int tile0, int S, hipStream_t st) {
   const int MT = (M + BM - 1) / BM, NTv = (a.N + BN - 1) / BN, ntiles = MT * NTv, ntail = ntiles - tile0;
-  constexpr int lds_stage = 2 * (BM + BN) * 128;
+  constexpr int lds_stage = STAGES * (BM + BN) * 128;
   constexpr int lds_epi = 4 * (BM / 2) * ((BN / 2) * 4 + 16);
   constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0) + 4 * 256;   // (the unsplit head tiles' bias / colsum rows, the prefetch landing zone)
-  auto kf = igemm_kernel<T, BM, BN, 2, 2, 2, false, false>;
-  auto ks = igemm_kernel<T, BM, BN, 2, 2, 2, false, true>;
+  auto kf = igemm_kernel<T, BM, BN, 2, 2, STAGES, false, false>;
+  auto ks = igemm_kernel<T, BM, BN, 2, 2, STAGES, false, true>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -992,10 +1000,27 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   static const bool split_off = getenv("SR_SPLITK") && atoi(getenv("SR_SPLITK")) == 0;      // tuning / A-B aid
   const int KT = a.KH * a.KH * ((a.C1 + a.C2) / (int)(128 / sizeof(T)));
   const int forceS = a.split > 1 ? a.split : 0;
-  const bool may_split = !TRANS && !split_off && a.split >= 0 && a.workspace && a.act != 2 && a.N % 4 == 0 && KT >= 32;
-  if (forceS && (!may_split || (force != 2 && force != 3)))
-    SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d needs tile 2 or 3, a workspace, no GEGLU / transposed output and K >= 32 steps", a.split);
+  const bool can_split = !TRANS && !split_off && a.split >= 0 && a.workspace && a.act != 2 && a.N % 4 == 0;
+  const bool may_split = can_split && KT >= 32;
+  // Deep-ring tiles for grids of less than one workgroup per CU (13 = 64x64 x 8 stages, 14 = 128x64 x 6, 15 = 128x128 x 4; 128-144
+  // KB of LDS, one workgroup per CU).  The 2-stage tiles above have ONE K-step of loads in flight per workgroup and rely on two
+  // or three co-resident workgroups to hide the rest of the latency; a launch with 40..160 workgroups (the 16x16 / 8x8 levels, any
+  // level of a one-view batch: M = 128..8192) has no co-resident partner, so every K-step cost a full L2 / HBM round trip --
+  // 20.8 us for M 512 K 1280 N 1280 (1.7 GFLOP, 4.6 MB).  Here the whole ring is requested up front (up to seven K-steps in
+  // flight per workgroup, counted vmcnt as above); 14 / 15 also split K (from 8 K-steps on) so that a short loop is entirely in
+  // flight before its first MFMA.
+  const bool deep_split = can_split && KT >= 8 && (force == 14 || force == 15);
+  if (forceS && !((may_split && (force == 2 || force == 3)) || deep_split))
+    SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d needs tile 2 / 3 (K >= 32 steps) or 14 / 15 (K >= 8 steps), a workspace, no GEGLU / transposed output", a.split);
   if constexpr (!TRANS) {
+    if (deep_split && forceS) {
+      int tile0 = 0;
+      const int64_t tiles = force == 15 ? wg_128x128 : (int64_t)((M + 127) / 128) * n64;
+      const int S = plan_split(tiles, KT, 256, 1.0, 128 * (force == 15 ? 128 : 64) * 4, a.workspace_bytes, &tile0, forceS);
+      if (S < 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d does not fit this shape (K steps %d, workspace %lld B)", a.split, KT, (long long)a.workspace_bytes);
+      if (S > 1) return force == 15 ? launch_split<T, 128, 128, 4>(a, M, Ho, Wo, tile0, S, st) : launch_split<T, 128, 64, 6>(a, M, Ho, Wo, tile0, S, st);
+      SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d: nothing to split (whole rounds of workgroups only)", a.split);
+    }
     if (may_split && (force == 2 || force == 3)) {           // tuned tile + modelled (split 0) or given (split S) tail split
       int tile0 = 0;
       if (force == 2) {
@@ -1013,6 +1038,9 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   if (force == 2) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 3) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   if (force == 4) return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if (force == 13) return launch<T, 64, 64, 2, 2, 8, TRANS>(a, M, Ho, Wo, st);
+  if (force == 14) return launch<T, 128, 64, 2, 2, 6, TRANS>(a, M, Ho, Wo, st);
+  if (force == 15) return launch<T, 128, 128, 2, 2, 4, TRANS>(a, M, Ho, Wo, st);
   if (force == 8) {
     if constexpr (!TRANS && sizeof(T) == 2) { if (conv3p_ok(a, M)) return launch_conv3p(a, M, st); }
     SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 8 (patch-stationary 3x3) needs fp16, KH=3, stride 1, one source, N %% 320 == 0, "
@@ -1065,7 +1093,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     if (force == 5 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) >= 256))
       return launch<T, 256, 320, 4, 2, 2, TRANS, 128, 2>(a, M, Ho, Wo, st);
   } else {
-    if (force >= 5) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d is fp16, non-transposed only", force);
+    if (force >= 5 && force <= 12) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d is fp16, non-transposed only", force);
   }
   const int64_t wg_256x128 = (int64_t)((M + 255) / 256) * n128;
   const bool big = !waste128 && wg_256x128 >= 512;
@@ -1097,6 +1125,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   if (!waste128 && wg_128x128 >= 192 && !(a.KH == 1 && wg_128x128 <= 768)) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   const int64_t wg_128x64 = (int64_t)((M + 127) / 128) * n64;
   if (wg_128x64 >= 192) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if ((int64_t)((M + 63) / 64) * n64 <= 256 && KT >= 4) return launch<T, 64, 64, 2, 2, 8, TRANS>(a, M, Ho, Wo, st);   // no co-resident partner: deep ring
   return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
 }
 
@@ -1116,7 +1145,7 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
   if (a->row_stats && !a->colsum) SR_FAIL(SR_ERR_INVALID, "sr_igemm: row_stats without colsum");
   if (a->row_stats && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
-  if (a->tile < 0 || a->tile > 12 || a->split < -1 || a->split == 1 || a->split > 16) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
+  if (a->tile < 0 || a->tile > 15 || a->split < -1 || a->split == 1 || a->split > 16) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample && ((a->up_h > 0) != (a->up_w > 0))) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w go together");
   if (!a->upsample && (a->up_h || a->up_w)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w without upsample");

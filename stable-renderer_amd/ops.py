@@ -136,14 +136,76 @@ def save_tune_table(path):
         _json.dump({_json.dumps([int(x) for x in k]): list(v) for k, v in sorted(_TUNED.items())}, f, indent=0)
 
 
-_CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (2, 2), (2, 3), (2, 4), (2, 6), (2, 8), (3, 0), (3, -1), (3, 2), (3, 3), (3, 4), (3, 6), (3, 8), (4, -1), (5, -1), (6, -1), (7, -1), (8, -1), (9, -1), (10, -1), (11, -1), (12, -1))
+_CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (2, 2), (2, 3), (2, 4), (2, 6), (2, 8), (3, 0), (3, -1), (3, 2), (3, 3), (3, 4), (3, 6), (3, 8), (4, -1), (5, -1), (6, -1), (7, -1), (8, -1), (9, -1), (10, -1), (11, -1), (12, -1),
+               (13, -1), (14, -1), (14, 2), (14, 3), (14, 4), (14, 5), (15, -1), (15, 2), (15, 3), (15, 4), (15, 5))
 
 
 def autotune_enabled():
     return os.environ.get("SR_AUTOTUNE", "1") != "0" and torch.cuda.is_available()
 
 
-def tune_igemm(ar, min_flops=1.0e9, reps=4, allow_split=True):
+# Every timed launch runs behind a pass over a buffer larger than the 256 MB Infinity Cache plus a read of the layer's activations
+# (sr_cache_touch): weights in HBM, inputs fresh from the previous kernel -- what a layer meets inside a UNet evaluation, whose
+# 1.7 GB of weights never stay cached from one evaluation to the next.  Back-to-back timing (SR_TUNE_COLD=0, the form of rounds
+# 1-3) favours tiles that rely on cache-resident weights: same box, B = 16 evaluation 19.55 -> 18.99 ms, B = 2 7.56 -> 7.03 ms.
+_TUNE_COLD = os.environ.get("SR_TUNE_COLD", "1") == "1"
+_FLUSH = {}
+
+
+def _tune_cold(ar, sig, allow_split, reps):
+    lib, st = L.lib(), stream_ptr()
+    dev = torch.cuda.current_device()
+    if dev not in _FLUSH:
+        _FLUSH[dev] = torch.empty(320 << 20, dtype=torch.uint8, device="cuda")
+    flush = _FLUSH[dev]
+
+    es = 2 if ar.dtype == L.SR_F16 else 4
+    Ho, Wo = ((ar.up_h or 2 * ar.H), (ar.up_w or 2 * ar.W)) if ar.upsample else ((ar.H + ar.stride - 1) // ar.stride, (ar.W + ar.stride - 1) // ar.stride)
+    warm = [(ar.a, ar.B * ar.H * ar.W * ar.C1 * es)]         # what the previous kernels of a plan have just written
+    if ar.a2 and ar.C2:
+        warm.append((ar.a2, ar.B * ar.H * ar.W * ar.C2 * es))
+    if ar.residual:
+        warm.append((ar.residual, ar.B * Ho * Wo * ar.N * es))
+
+    def timed(n):
+        tot = 0.0
+        for _ in range(n):
+            flush.add_(1)
+            for ptr, nbytes in warm:
+                lib.sr_cache_touch(ptr, nbytes, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lib.sr_igemm(C.byref(ar), st)
+            e1.record()
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / n
+    times = {}
+    for tile, split in _CANDIDATES:
+        if ((ar.act == 2 or ar.transpose_out) and split >= 0 and tile != 0) or (not allow_split and split >= 0):
+            continue
+        ar.tile, ar.split = tile, split
+        if lib.sr_igemm(C.byref(ar), st) != 0:
+            continue
+        times[(tile, split)] = timed(reps)
+    for c in sorted(times, key=times.get)[:4]:               # play-off of the four fastest, minimum of the two samples
+        ar.tile, ar.split = c
+        times[c] = min(times[c], timed(3 * reps))
+    best, best_t = (0, 0 if allow_split else -1), None
+    for c in _CANDIDATES:
+        if c in times and (best_t is None or times[c] < best_t * 0.97):
+            best, best_t = c, times[c]
+    _TUNED[sig] = best
+    if _TUNE_CACHE:
+        import json as _json
+        with open(_TUNE_CACHE, "w") as _f:
+            _json.dump({_json.dumps([int(x) for x in k]): list(v) for k, v in _TUNED.items()}, _f)
+    if os.environ.get("SR_AUTOTUNE_LOG"):
+        print(f"[tune cold] B{ar.B} {ar.H}x{ar.W} C{ar.C1}+{ar.C2} N{ar.N} k{ar.KH} s{ar.stride} u{ar.upsample} act{ar.act} "
+              f"t{ar.transpose_out} -> tile {best[0]} split {best[1]}  {best_t * 1e3:.1f} us", flush=True)
+
+
+def tune_igemm(ar, min_flops=2.0e8, reps=4, allow_split=True):
     """times the candidate (tile, split) settings of one op on the current stream and leaves the fastest in ``ar``"""
     Ho, Wo = ((ar.up_h or 2 * ar.H), (ar.up_w or 2 * ar.W)) if ar.upsample else ((ar.H + ar.stride - 1) // ar.stride, (ar.W + ar.stride - 1) // ar.stride)
     flops = 2.0 * ar.B * Ho * Wo * ar.N * ar.KH * ar.KH * (ar.C1 + ar.C2)
@@ -154,6 +216,10 @@ def tune_igemm(ar, min_flops=1.0e9, reps=4, allow_split=True):
     if sig not in _TUNED:
         lib, st = L.lib(), stream_ptr()
         times = {}
+        if _TUNE_COLD:
+            _tune_cold(ar, sig, allow_split, reps)
+            ar.tile, ar.split = _TUNED[sig]
+            return
         for rnd in range(2):                                 # two interleaved rounds, min per candidate (clock ramp, noise)
             for tile, split in _CANDIDATES:
                 if (ar.act == 2 or ar.transpose_out) and split >= 0 and tile != 0:

@@ -136,7 +136,7 @@ def test_igemm(ops, dtype, case):
     close(got, ref, dtype, scale=ref.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15])
 @pytest.mark.parametrize("act", [0, 2])
 def test_igemm_forced_tiles(ops, tile, act):
     """every tile configuration the tuner may pin (sr_igemm_args.tile), incl. the 256x320 tiles with 2 x 128-byte and
@@ -170,6 +170,45 @@ def test_igemm_forced_tiles(ops, tile, act):
     torch.cuda.synchronize()
     got = out.float().cpu().reshape(B, H, W, nout).permute(0, 3, 1, 2)
     close(got, ref, dtype, scale=ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(13, -1, 2, 1, False), (13, -1, 7, 1, False), (13, -1, 3, 3, False), (13, -1, 9, 1, True),
+                                  (14, -1, 5, 1, False), (14, 2, 8, 1, False), (14, 4, 2, 3, False), (14, 5, 3, 3, False),
+                                  (15, -1, 3, 1, False), (15, 2, 10, 1, False), (15, 3, 4, 3, False)])
+def test_igemm_deep_ring_tiles(ops, dtype, case):
+    """tiles 13 / 14 / 15 (8 / 6 / 4 LDS stages, the whole ring requested up front): K loops shorter than the ring, exactly as
+    long, and longer (steady state + counted drain), ragged M and N, bias + time-embedding slice + residual, forced split-K from
+    8 K-steps on (partials + fixed-order reduce), transposed output"""
+    tile, split, ksteps, KH, trans = case
+    dev = "cuda"
+    ke = ops.kelems(dtype)
+    B, H, W, C1, N = 3, 7, 9, ksteps * ke, 200
+    x = rnd(1, B, C1, H, W)
+    w = rnd(2, N, C1, KH, KH) * (C1 * KH * KH) ** -0.5
+    bias, rowvec, resid = rnd(3, N) * 0.1, rnd(4, B, N), rnd(5, B, N, H, W)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), bias, padding=KH // 2)
+    xa = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    wp, bp = ops.pack_conv_weight(w, dtype).to(dev), ops.pack_bias(bias).to(dev)
+    M = B * H * W
+    if trans:
+        ldt = (H * W + 7) // 8 * 8
+        out = torch.zeros(B, N, ldt, dtype=dtype, device=dev)
+        ops.igemm(xa, wp, out, B, H, W, C1, N, KH=KH, bias=bp, transpose_out=1, ldt=ldt, tile=tile, split=split)
+        torch.cuda.synchronize()
+        close(out[:, :, :H * W].float().cpu(), ref.reshape(B, N, H * W), dtype, scale=ref.abs().max().item())
+        return
+    ref = ref + rowvec[:, :, None, None] + resid.to(dtype).float()
+    out = torch.zeros(M, N, dtype=dtype, device=dev)
+    rs = resid.permute(0, 2, 3, 1).reshape(M, N).contiguous().to(dtype).to(dev)
+    ops.igemm(xa, wp, out, B, H, W, C1, N, KH=KH, bias=bp, rowvec=rowvec.to(dev), residual=rs, tile=tile, split=split)
+    torch.cuda.synchronize()
+    close(out.float().cpu().reshape(B, H, W, N).permute(0, 3, 1, 2), ref, dtype, scale=ref.abs().max().item())
+    if split > 1:                                           # the split form is bit-reproducible (fixed-order reduce, no atomics)
+        again = torch.zeros_like(out)
+        ops.igemm(xa, wp, again, B, H, W, C1, N, KH=KH, bias=bp, rowvec=rowvec.to(dev), residual=rs, tile=tile, split=split)
+        torch.cuda.synchronize()
+        assert torch.equal(out, again)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 64, 128, 320), (4, 32, 32, 192, 640), (5, 16, 16, 64, 320), (8, 8, 8, 256, 320),

@@ -1,4 +1,4 @@
-"""Per-op timing of a launch plan on the GPU (development tool): python tools/profile_plan.py [unet|vae] [f16|f32]"""
+"""Per-op timing of a launch plan on the GPU (development tool): [SR_VIEWS=n] python tools/profile_plan.py [unet|vae] [f16|f32] [seq]"""
 import ctypes as C
 import os
 import sys
@@ -14,9 +14,10 @@ from stable_renderer_amd.pipeline import build_sd15_pipeline  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "unet"
 dtype = torch.float16 if (len(sys.argv) < 3 or sys.argv[2] == "f16") else torch.float32
-pipe = build_sd15_pipeline(dtype=dtype, use_graph=False)
+VIEWS = int(os.environ.get("SR_VIEWS", "8"))
+pipe = build_sd15_pipeline(dtype=dtype, use_graph=False, n_views=VIEWS)
 if which == "unet":
-    p = pipe.runner._ensure_plan([3])
+    p = pipe.runner._ensure_plan([min(3, 2 * VIEWS - 1)])
     pipe.runner._load_ctx(p)
     plan = p["step"]
 else:
