@@ -1,13 +1,16 @@
 // EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 3; DESIGN.md section 5 "Round 3" (e)).  Kept for the next round.
-// It was wired into igemm.hip as sr_igemm_args.tile = 13 (dispatch: `if (force == 13) { if (geglu_xs_ok(a, M)) return launch_geglu_xs(a, M, st); }`).
+// It was wired into igemm.hip as its own sr_igemm_args.tile value (13 at the time; 13-15 are the deep-ring tiles now) (dispatch: `if (force == 13) { if (geglu_xs_ok(a, M)) return launch_geglu_xs(a, M, st); }`).
 // Status when it was taken out:
 //   * timing (M 65536, K 320, N 2560, one box): 201-208 us vs 199 us (256x320 tile) and 196 us (128x320 tile): no gain;
 //     ablations: without the epilogue 114.5 us = 938 TF/s (the GEGLU epilogue is 43 % of the kernel), without W staging 178 us;
-//   * correctness: parity-clean at K = 320 (8 chunks) in every run, but at K = 128, N = 640 (KS = 4, two chunks) 190 of 200
-//     launches produced wrong values at lane 31 of waves 4..7 (output row 95 of the tile, columns tn*8 + 2, +3 for tn >= 1 of chunk 0);
-//     with `s_waitcnt vmcnt(0)` at every step (SR_GX_DBG=3) 0 of 200.  So one of the counted waits is not sufficient although the
-//     operation counts check out on paper -- the suspicion is the retirement order of the asm-issued stores relative to older
-//     LDS-DMA loads (the counts assume one in-order queue).  Unresolved => not shipped.
+//   * correctness: parity-clean at K = 320 (8 chunks) in every run, but at K = 128, N = 640 (KS = 4, two chunks) 190-200 of 200
+//     launches produced wrong values (lane 31 of waves 4..7, or NaN).  RESOLVED after it was taken out: the epilogue's
+//     `global_store_dwordx4` statements were issued from inline asm WITHOUT the `s_nop 1` that hipcc pads a >64-bit store with
+//     (the instruction after it may overwrite the store's data registers before the store has read them; hipcc does not model
+//     what is inside an asm string).  With `s_nop 1` inside both store strings: 0 of 200 bad launches at K = 128 and K = 320,
+//     output bit-identical to the 256x320 tile's.  The counted vmcnt waits were right.  (The earlier observation "vmcnt(0) at
+//     every step fixes it" changed the schedule around the stores, not the ordering.)
+//   * so the kernel is ordered, but still no faster than the tile kernels => not shipped; next step = deferred epilogue.
 // ---- X-stationary GEGLU (tile 13): 128 x (all of N), 8 waves -----------------------------------------------------------------
 // The K-short GEGLU projection of a transformer block (ff.net.0: K = C = 320, N = 8C; attention.py:60-90) through the tile kernels
 // above is one workgroup per 256 x 320 output tile: ~20 us of lifetime of which ~10 are MFMA (3 us of ramp -- arguments, first
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(512, 1) void geglu_xs_kernel(const sr_igemm_args p,
       const u32x4 d1 = *(const u32x4*)(stg + r1 * STG_ROWB + k1 * 16);
       char* a0 = obase + (int64_t)(tm * 16 + r0) * ldo * 2 + k0 * 16;
       char* a1 = obase + (int64_t)(tm * 16 + r1) * ldo * 2 + k1 * 16;
-      asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a0), "v"(d0) : "memory");
-      asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a1), "v"(d1) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(a0), "v"(d0) : "memory");   // s_nop 1: see the header
+      asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(a1), "v"(d1) : "memory");
       __builtin_amdgcn_wave_barrier();                       // (LDS is in order per wave: the next pass may overwrite)
     }
     if constexpr (DBG == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
