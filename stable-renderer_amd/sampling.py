@@ -7,6 +7,7 @@ the k-diffusion loops ``sample_euler`` / ``sample_ddpm`` / ``sample_lcm`` (comfy
 once on the host; everything per step (UNet plan, CFG, sampler update, latent overlap) runs as HIP kernels.
 """
 import math
+import os
 
 import torch
 
@@ -23,6 +24,8 @@ def latent_scale_of(unet_cfg):
 SCHEDULER_NAMES = ["normal", "karras", "exponential", "sgm_uniform", "simple", "ddim_uniform"]
 SAMPLER_NAMES = ["euler", "ddim", "ddpm", "lcm"]
 
+
+_GRAPH_SEGMENTS = os.environ.get("SR_SHARD_GRAPH_SEGMENTS", "0") == "1"
 
 class ModelSamplingDiscrete:
     def __init__(self, linear_start=0.00085, linear_end=0.012, timesteps=1000):
@@ -161,6 +164,7 @@ class DiffusionRunner:
         self.copies = 1 if math.isclose(self.cfg_scale, 1.0) else 2     # samplers.py:335 (skip uncond at cfg 1)
         self.n_ctx = n_ctx
         self.use_graph = use_graph
+        self.graph_segments = _GRAPH_SEGMENTS               # view shard: replay the cut plan segments as hipGraphs (see _sharded_eval)
         self.ms = ModelSamplingDiscrete()
         self.latent_scale = latent_scale_of(unet.cfg)   # process_latent_in / process_latent_out (samplers.py:905, :933)
         self._plan = None
@@ -425,7 +429,12 @@ class DiffusionRunner:
         ``time_comm``) accumulates the time the compute stream spent stalled in those waits = the EXPOSED communication."""
         from . import parallel as PAR
         sched = p["schedule"]
-        if self.use_graph and not p.get("_segments_captured"):       # (per plan: conditioning lists run several plans per step)
+        # The 33 segments of an evaluation are launched eagerly (sr_plan_run) unless SR_SHARD_GRAPH_SEGMENTS=1 / runner.graph_segments: a hipGraphLaunch per
+        # segment costs more start-up latency than the ~12 kernels of a segment save in launch gaps -- measured as one rank of a
+        # shard (world-1 RCCL group, same box): 154.2 -> 148.1 ms per call at one view per rank, 197.3 -> 191.0 at two, 277.0 ->
+        # 270.0 at four.
+        use_graph = self.use_graph and self.graph_segments
+        if use_graph and not p.get("_segments_captured"):            # (per plan: conditioning lists run several plans per step)
             torch.cuda.current_stream().synchronize()
             for kind, *rest in sched:                       # all captures up front: none while a collective is in flight
                 if kind == "run" and rest[0].n > 0:
@@ -436,7 +445,7 @@ class DiffusionRunner:
         pending = []
         for kind, *rest in sched:
             if kind == "run":
-                rest[0].launch() if self.use_graph else rest[0].run()
+                rest[0].launch() if use_graph else rest[0].run()
             elif kind == "bcast":
                 for ln, src in rest[0]:                      # the rows and, with the folded LayerNorm, their statistics
                     for j, g in enumerate(self._inject_global):

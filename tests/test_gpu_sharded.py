@@ -155,6 +155,7 @@ def _lists_body(rank, world):
 
     def run(shard, graph):
         r = DiffusionRunner(net, N if shard is None else shard.n_local, h, w, 4.0, use_graph=graph, shard=shard)
+        r.graph_segments = graph
         r.set_cond_entries(entries_of(pos), entries_of(neg))
 
         def cb(ctx):
@@ -245,6 +246,7 @@ def _cn_body(rank, world):
 
     def run(shard, graph=False):
         pipe = build_sd15_pipeline(shard=shard, **dict(kw, use_graph=graph))
+        pipe.runner.graph_segments = graph
         torch.manual_seed(21)
         imgs = pipe.call().clone()
         torch.cuda.synchronize()
@@ -299,6 +301,7 @@ def _rccl_body(rank, world):
 
     def run(shard, graph):
         pipe = build_sd15_pipeline(shard=shard, use_graph=graph, **kw)
+        pipe.runner.graph_segments = graph
         pipe.runner.time_comm = shard is not None
         torch.manual_seed(7)
         imgs = pipe.call().clone()
