@@ -228,7 +228,7 @@ def main():
             sub.run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
+        reps = int(os.environ.get("SR_ROOFLINE_REPS", "5"))
         e0.record()
         for _ in range(reps):
             sub.run()
