@@ -14,7 +14,13 @@ namespace {
 
 // pixels per workgroup: 64 for UNet-sized maps, grows with HW so that a batch entry never has more than 64 chunks
 // (every apply block re-reduces its batch entry's partials; 64 chunks keeps that at 16 KB of L2 reads)
-__host__ __device__ inline int gn_ppc(int HW) { const int p = (HW + 63) / 64; return p < 64 ? 64 : p; }
+// Small batches get up to four times as many (smaller) chunks: with 64 chunks per entry a one-image launch is 64 workgroups on 256 CUs
+// (VAE decoder of one view: 0.93 TB/s on the 512 x 512 x 128 map against 4.5 TB/s at eight views; partials then 64 KB per entry).
+__host__ __device__ inline int gn_ppc(int HW, int B) {
+  const int chunks = B >= 8 ? 64 : B >= 4 ? 128 : 256;
+  const int p = (HW + chunks - 1) / chunks;
+  return p < 64 ? 64 : p;                                   // (16-pixel chunks for small batches measured the same: two launches bound those)
+}
 
 template <typename T>
 __device__ __forceinline__ void load_chunk(const T* p, float (&v)[sr_traits<T>::EPC]) {
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x1,
   const int nps = pp_ >= 1 ? pp_ : 1;               // pixel slices held in LDS
   float* chs = (float*)smem_raw;                    // [nps][C] per-channel sums
   float* chq = chs + nps * C;                       // [nps][C] per-channel sums of squares
-  const int ppc = gn_ppc(HW);
+  const int ppc = gn_ppc(HW, gridDim.y);
   const int p0 = chunk * ppc;
   const int p1 = min(HW, p0 + ppc);
   const int pp = 256 / cpt;                        // pixels processed in parallel when cpt <= 256
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
   float* sh = sc + C;
   float* gm = sh + C;      // [groups] mean, [groups] rstd
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const int ppc = gn_ppc(HW);
+  const int ppc = gn_ppc(HW, gridDim.y);
   const int p0 = chunk * ppc;
   const int p1 = min(HW, p0 + ppc);
   const int total = (p1 - p0) * cpt;
@@ -236,6 +242,8 @@ __global__ __launch_bounds__(BLOCK) void gn_fused_kernel(const T* __restrict__ x
   float* chs = (float*)smem_raw;                    // [pp][span] per-thread partials
   float* chsum = chs + pp * span;                   // [span]
   float* gstat = chsum + span;                      // [GB]
+  float* strip = gstat + GB;                        // [NS][span] first-level sums
+  const int NS = BLOCK / span;                      // strips of the two-level column sum (span <= 256 <= BLOCK)
   // bundles of one batch entry interleave inside the same cache lines: keep them on one XCD (one L2), close in time
   const int nb = groups / GB, wg = sr_xcd_remap(blockIdx.x, gridDim.x);
   const int b = wg / nb, bundle = wg - b * nb, tid = threadIdx.x;
@@ -268,9 +276,19 @@ __global__ __launch_bounds__(BLOCK) void gn_fused_kernel(const T* __restrict__ x
       for (int e = 0; e < EPC; ++e) chs[ps * span + cl + e] = acc[e];
     }
     __syncthreads();
+    // column sums in two fixed-order levels: strip s adds rows s, s + NS, ... (all threads busy), then span threads add the NS
+    // strips -- pp / NS + NS dependent adds instead of pp (512 for the 1024-thread form: a third of the kernel's time at small
+    // batches, where nothing else runs beside the 16..64 workgroups of a launch)
+    if (tid < NS * span) {
+      const int c = tid % span, s0 = tid / span;
+      float t = 0.f;
+      for (int q = s0; q < pp; q += NS) t += chs[q * span + c];
+      strip[s0 * span + c] = t;
+    }
+    __syncthreads();
     if (tid < span) {
       float t = 0.f;
-      for (int q = 0; q < pp; ++q) t += chs[q * span + tid];
+      for (int q = 0; q < NS; ++q) t += strip[q * span + tid];
       chsum[tid] = t;
     }
     __syncthreads();
@@ -331,7 +349,7 @@ template <typename T, int NV, int BLOCK>
 void launch_gn_fused(const sr_groupnorm_args* a, int GB, hipStream_t st) {
   constexpr int EPC = sr_traits<T>::EPC;
   const int C = a->C1 + a->C2, span = GB * (C / a->groups), vpp = span / EPC, pp = BLOCK / vpp;
-  const size_t lds = (size_t)(pp * span + span + GB) * sizeof(float);
+  const size_t lds = (size_t)(pp * span + span + GB + (BLOCK / span) * span) * sizeof(float);
   hipLaunchKernelGGL((gn_fused_kernel<T, NV, BLOCK>), dim3((a->groups / GB) * a->B), dim3(BLOCK), lds, st, (const T*)a->x, (const T*)a->x2,
                      a->gamma, a->beta, (T*)a->y, a->HW, a->C1, a->C2, a->groups, GB, a->eps, a->silu);
 }
@@ -346,7 +364,7 @@ bool try_gn_fused(const sr_groupnorm_args* a, hipStream_t st) {
     if ((g * cpg) % EPC == 0 && a->groups % g == 0) { GB = g; break; }
   if (!GB) return false;
   const int vpp = GB * cpg / EPC;
-  if (vpp > 256) return false;
+  if (vpp > 256 || GB * cpg > 256) return false;             // (the column sums are taken by `span` threads of a >= 256-thread block)
   const int need256 = sr_cdiv(a->HW, 256 / vpp), need1024 = sr_cdiv(a->HW, 1024 / vpp);
   if (need256 <= 4) launch_gn_fused<T, 4, 256>(a, GB, st);
   else if (need256 <= 8) launch_gn_fused<T, 8, 256>(a, GB, st);
@@ -526,7 +544,7 @@ extern "C" int sr_row_stats(const void* x, float* stats, int32_t rows, int32_t C
 }
 
 extern "C" int64_t sr_groupnorm_scratch_floats(int32_t B, int32_t HW) {
-  return (int64_t)B * sr_cdiv(HW, gn_ppc(HW)) * 64 * 2;
+  return (int64_t)B * sr_cdiv(HW, gn_ppc(HW, B)) * 64 * 2;
 }
 
 extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
@@ -536,7 +554,7 @@ extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
   if (a->groups <= 0 || a->groups > 64 || C % a->groups) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C=%d groups=%d", C, a->groups);
   if (a->C1 % epc || a->C2 % epc) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: channels must be multiples of %d", epc);
   if (a->C2 > 0 && !a->x2) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C2>0 without x2");
-  const int nchunk = sr_cdiv(a->HW, gn_ppc(a->HW));
+  const int nchunk = sr_cdiv(a->HW, gn_ppc(a->HW, a->B));
   if (a->groups > 32) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: at most 32 groups");
   const size_t lds = (size_t)(2 * C + 2 * a->groups + 16 * a->groups) * sizeof(float);
   if (lds > 64 * 1024) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C too large");

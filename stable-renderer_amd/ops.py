@@ -165,7 +165,7 @@ def _tune_cold(ar, sig, allow_split, reps):
     if ar.a2 and ar.C2:
         warm.append((ar.a2, ar.B * ar.H * ar.W * ar.C2 * es))
     if ar.residual:
-        warm.append((ar.residual, ar.B * Ho * Wo * ar.N * es))
+        warm.append((ar.residual, ar.B * Ho * Wo * (ar.N // 2 if ar.act == 2 else ar.N) * es))
 
     def timed(n):
         tot = 0.0
@@ -213,13 +213,11 @@ def tune_igemm(ar, min_flops=2.0e8, reps=4, allow_split=True):
         return
     sig = (ar.dtype, ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample, ar.act, ar.transpose_out, ar.out_f32,
            bool(ar.residual), bool(ar.rowvec), bool(allow_split), bool(ar.row_stats), ar.pad_br, ar.up_h, ar.up_w)
-    if sig not in _TUNED:
+    if sig not in _TUNED and _TUNE_COLD:
+        _tune_cold(ar, sig, allow_split, reps)
+    if sig not in _TUNED:                                    # SR_TUNE_COLD=0: back-to-back timing
         lib, st = L.lib(), stream_ptr()
         times = {}
-        if _TUNE_COLD:
-            _tune_cold(ar, sig, allow_split, reps)
-            ar.tile, ar.split = _TUNED[sig]
-            return
         for rnd in range(2):                                 # two interleaved rounds, min per candidate (clock ramp, noise)
             for tile, split in _CANDIDATES:
                 if (ar.act == 2 or ar.transpose_out) and split >= 0 and tile != 0:

@@ -211,6 +211,35 @@ def test_igemm_deep_ring_tiles(ops, dtype, case):
         assert torch.equal(out, again)
 
 
+def test_cold_state_tuner_and_cache_touch(ops, monkeypatch):
+    """the tile tuner's measurement state (cache flush + sr_cache_touch of the activations / residual): sr_cache_touch accepts any
+    16-byte-aligned range and rejects null / unaligned pointers; a freshly tuned shape (not in any table) ends on a legal
+    (tile, split) whose result equals the heuristic tile's within the GEMM tolerance"""
+    import ctypes as C
+    lib, st = ops.L.lib(), ops.stream_ptr()
+    buf = torch.randn(1 << 20, dtype=torch.float16, device="cuda")
+    assert lib.sr_cache_touch(buf.data_ptr(), buf.numel() * 2, st) == 0
+    assert lib.sr_cache_touch(buf.data_ptr(), 0, st) == 0
+    assert lib.sr_cache_touch(None, 64, st) != 0
+    assert lib.sr_cache_touch(buf.data_ptr() + 2, 64, st) != 0
+    dtype, dev = torch.float16, "cuda"
+    B, H, W, C1, N = 1, 24, 24, 1280, 1280                   # M = 576: less than one workgroup per CU on every tile
+    x, w = rnd(1, B, C1, H, W), rnd(2, N, C1, 3, 3) * (C1 * 9) ** -0.5
+    resid = rnd(5, B, N, H, W)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), None, padding=1) + resid.to(dtype).float()
+    xa = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    wp = ops.pack_conv_weight(w, dtype).to(dev)
+    rs = resid.permute(0, 2, 3, 1).reshape(H * W, N).contiguous().to(dtype).to(dev)
+    out = torch.zeros(H * W, N, dtype=dtype, device=dev)
+    ar = ops.igemm_args(xa, wp, out, B, H, W, C1, N, KH=3, residual=rs)
+    monkeypatch.setattr(ops, "_TUNE_COLD", True)
+    ops.tune_igemm(ar)
+    assert (ar.tile, ar.split) in ops._CANDIDATES
+    assert lib.sr_igemm(C.byref(ar), st) == 0
+    torch.cuda.synchronize()
+    close(out.float().cpu().reshape(B, H, W, N).permute(0, 3, 1, 2), ref, dtype, scale=ref.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 64, 128, 320), (4, 32, 32, 192, 640), (5, 16, 16, 64, 320), (8, 8, 8, 256, 320),
                                    (1, 64, 64, 64, 320), (2, 16, 32, 128, 320)])
 @pytest.mark.parametrize("act", [0, 1])
