@@ -6,11 +6,15 @@
 //                  28.4 fixed-point snapping, integer edge setup, pixel bbox; writes a 256-byte TriRec.
 //   raster_tiles : one 256-thread workgroup per 16x16 pixel tile, one thread per pixel.  The workgroup walks the
 //                  draw's triangles in index order, bins the ones whose bbox touches the tile into LDS (ballot +
-//                  prefix compaction keeps primitive order), stages their TriRecs in LDS, and every thread evaluates
+//                  prefix compaction keeps primitive order; the bounding boxes come from a dense 16-byte-per-triangle array
+//                  behind the TriRecs), stages their TriRecs in LDS, and every thread evaluates
 //                  coverage / depth / the fragment shader (default_Gbuffer.frag.glsl:100-257) for its own pixel with the
 //                  pixel's state in registers.  Each pixel is read at most once (lazily, the pre-draw "snapshot") and
 //                  written at most once per draw: 68 B/pixel of HBM traffic, no atomics, no inter-workgroup traffic,
 //                  and results independent of scheduling (bit-identical to oracle/raster_ref.c, which defines the rule).
+//                  (Measured and not kept: every lane searching its own next covering fragment and all lanes then shading
+//                  together -- one shader pass per fragment layer instead of one per triangle touching the wave: the
+//                  per-lane record reads cost more than the passes saved, 24.4 -> 28.3 us on the bench sphere.)
 // Built with -ffp-contract=off: the fp32 evaluation order below IS the specification.
 #include "sr_common.h"
 
@@ -165,6 +169,9 @@ __global__ void raster_setup(const sr_draw d, TriRec* __restrict__ recs, int W, 
     }
   }
   recs[t] = r;
+  // binning reads ONLY this: a 16-byte lane-contiguous record instead of 16 bytes out of every 256-byte TriRec (one 128-byte
+  // line per lane); a culled / degenerate triangle gets a box no tile meets
+  ((int4*)(recs + d.nt))[t] = r.valid ? make_int4(r.x0, r.x1, r.y0, r.y1) : make_int4(0x7fffffff, -1, 0x7fffffff, -1);
 }
 
 __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gbuffer g, const TriRec* __restrict__ recs) {
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gb
       bb[c] = make_int4(1, 0, 1, 0);
       valid[c] = 0;
       if (ti < d.nt) {
-        bb[c] = *(const int4*)&recs[ti].x0;                 // x0,x1,y0,y1
-        valid[c] = recs[ti].valid;
+        bb[c] = ((const int4*)(recs + d.nt))[ti];           // x0,x1,y0,y1 (raster_setup's dense copy)
+        valid[c] = 1;
       }
     }
     unsigned long long m[BIN_CH];
@@ -437,7 +444,7 @@ __global__ void gbuffer_clear_kernel(const sr_gbuffer g) {
 
 }  // namespace
 
-extern "C" int64_t sr_raster_scratch_bytes(int32_t nt, int32_t, int32_t) { return (int64_t)nt * (int64_t)sizeof(TriRec); }
+extern "C" int64_t sr_raster_scratch_bytes(int32_t nt, int32_t, int32_t) { return (int64_t)nt * (int64_t)(sizeof(TriRec) + sizeof(int4)); }
 
 // ---- identical-G-buffer merge (renderManager.py:118-133): an object drawn ALONE into a cleared G-buffer is folded into the
 // accumulated planes wherever its depth (normal_depth.a = 1 - window z: closer = larger, compared in fp16 as stored) beats theirs
