@@ -361,13 +361,20 @@ typedef struct {
   int32_t has_vertex_color, depth_test, cull_back;
   int32_t id_w, id_h;                                       /* texcoord-id grid (diffuse or corr-map size) */
   const void* noise_tex; int32_t noise_w, noise_h;          /* RGBA16F NEAREST or NULL */
-  const void* diffuse_tex; int32_t diffuse_w, diffuse_h;    /* RGBA32F NEAREST or NULL */
+  const void* diffuse_tex; int32_t diffuse_w, diffuse_h;    /* RGBA32F or NULL; NEAREST unless diffuse_levels >= 2 (below) */
   const void* corrmap_tex; int32_t corr_w, corr_h;          /* fp16 (k*k, h, w, 4) for render_mode 1 or NULL */
   /* tangent-space normal map (default_Gbuffer.frag.glsl:114-123, vert.glsl:52-53): all three or none.  view normal =
    * normalize(MV_IT * normalize(TBN * normalize(tex.rgb*2-1))), TBN columns = interpolated normalize(tangent), normalize(bitangent),
    * raw normal */
   const float* tangent; const float* bitangent;             /* per-vertex [nv,3] fp32 or NULL */
   const void* normal_tex; int32_t normal_w, normal_h;       /* RGBA32F NEAREST or NULL */
+  int32_t diffuse_levels;                                   /* 0 / 1: diffuse_tex is one level, sampled NEAREST.  >= 2: the level-0 image is
+                                                               followed by its mip chain (level k = max(1, w >> k) x max(1, h >> k) texels,
+                                                               RGBA32F, scene.build_mip_chain) and sampled TRILINEAR with REPEAT -- the
+                                                               reference's default for file textures (GL_LINEAR_MIPMAP_LINEAR / GL_LINEAR,
+                                                               engine/static/texture/texture.py:57-60, 276-289; anisotropy not restated).
+                                                               Level of detail from the perspective-correct uv of the same triangle one
+                                                               pixel right / down; fixed fp32 order = oracle/raster_ref.c tex_trilinear */
 } sr_draw;
 typedef struct {
   void* color;      /* [H,W,4] fp16 */

@@ -20,7 +20,8 @@
  *     such triangles in the reference (its scenes keep geometry in front of the camera): this path is defined here;
  *   - barycentrics b_i = (float)E_i / (float)area, perspective-correct attributes sum(a_i b_i/w_i) / sum(b_i/w_i)
  *     in the association order written below, window depth z = sum(z_i b_i), GL_LESS against a 1.0-cleared buffer;
- *   - flat vertexID = last vertex of the triangle (GL provoking vertex), textures sampled NEAREST with REPEAT;
+ *   - flat vertexID = last vertex of the triangle (GL provoking vertex), textures sampled NEAREST with REPEAT (a diffuse
+ *     texture handed over with its mip chain, diffuse_levels >= 2, is sampled trilinear: tex_trilinear below);
  *   - fp32 only, no fused multiply-add (built with -ffp-contract=off), IEEE sqrt/div, fp16 stores round-to-nearest-even.
  * Triangles are processed in index order; every fragment of a draw sees the G-buffer as it was BEFORE the draw
  * (the reference copies all six targets after each draw task), and the last passing fragment of a pixel wins.
@@ -46,6 +47,7 @@ typedef struct {
   const uint16_t* corrmap_tex; int32_t corr_w, corr_h;
   const float* tangent; const float* bitangent;              /* per-vertex, for the TBN normal-map branch (frag:118-122) */
   const float* normal_tex; int32_t normal_w, normal_h;       /* RGBA32F */
+  int32_t diffuse_levels;                                    /* >= 2: mip chain behind level 0, sampled trilinear (see tex_trilinear) */
 } ref_draw;
 
 typedef struct {
@@ -98,6 +100,52 @@ static int nearest_index(float t, int n) {        /* REPEAT + NEAREST */
   if (i >= n) i = n - 1;
   if (i < 0) i = 0;
   return i;
+}
+
+/* ---- trilinear sampling of a mip-mapped RGBA32F texture (the reference's file textures: GL_LINEAR_MIPMAP_LINEAR / GL_LINEAR,
+ * GL_REPEAT, engine/static/texture/texture.py:57-60, 276-289; anisotropy not restated).  OpenGL 4.6 section 8.14 in fp32 with a
+ * fixed operation order: levels are stored one behind the other (level k = max(1, w >> k) x max(1, h >> k) texels, box-filtered
+ * by the host), rho^2 = max(|d(u,v)/dx|^2, |d(u,v)/dy|^2) in level-0 texels, lambda = log2(rho) from the exponent of rho^2 and
+ * a cubic for the mantissa (|err| < 1.5e-4: far below the 8-bit LOD fraction of GL hardware, and the same bits in C and HIP,
+ * which libm's log2f would not give). */
+static int tex_wrap(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+static void tex_bilinear(const float* lvl, int w, int h, float s, float t, float* o) {
+  const float u = s * (float)w - 0.5f, v = t * (float)h - 0.5f;
+  const float fu = floorf(u), fv = floorf(v);
+  const float a = u - fu, b = v - fv;
+  const int i0 = tex_wrap((int)fu, w), i1 = tex_wrap(i0 + 1, w), j0 = tex_wrap((int)fv, h), j1 = tex_wrap(j0 + 1, h);
+  const float* t00 = lvl + ((size_t)j0 * w + i0) * 4; const float* t10 = lvl + ((size_t)j0 * w + i1) * 4;
+  const float* t01 = lvl + ((size_t)j1 * w + i0) * 4; const float* t11 = lvl + ((size_t)j1 * w + i1) * 4;
+  for (int k = 0; k < 4; ++k) {
+    const float top = t00[k] * (1.0f - a) + t10[k] * a, bot = t01[k] * (1.0f - a) + t11[k] * a;
+    o[k] = top * (1.0f - b) + bot * b;
+  }
+}
+static const float* tex_level(const float* tex, int w, int h, int level, int* lw, int* lh) {
+  size_t off = 0;
+  for (int k = 0; k < level; ++k) { off += (size_t)w * h * 4; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; }
+  *lw = w; *lh = h;
+  return tex + off;
+}
+static void tex_trilinear(const float* tex, int w, int h, int levels, float s, float t, float rho2, float* o) {
+  int lw, lh;
+  s = s - floorf(s); t = t - floorf(t);
+  if (!(rho2 > 1.0f) || levels <= 1) { tex_bilinear(tex, w, h, s, t, o); return; }       /* magnification (and NaN): level 0 */
+  uint32_t bits; memcpy(&bits, &rho2, 4);
+  const int e = (int)(bits >> 23) - 127;
+  bits = (bits & 0x7fffffu) | 0x3f800000u;
+  float m; memcpy(&m, &bits, 4);
+  const float z = m - 1.0f;
+  const float l2m = z * (1.4380732774734497f + z * (-0.6747666597366333f + z * (0.31700071692466736f + z * -0.08030730485916138f)));
+  const float lam = 0.5f * ((float)e + l2m);
+  const int maxl = levels - 1;
+  if (!(lam < (float)maxl)) { const float* l = tex_level(tex, w, h, maxl, &lw, &lh); tex_bilinear(l, lw, lh, s, t, o); return; }
+  const int d1 = (int)lam;
+  const float fr = lam - (float)d1;
+  float c1[4], c2[4];
+  const float* l1 = tex_level(tex, w, h, d1, &lw, &lh); tex_bilinear(l1, lw, lh, s, t, c1);
+  const float* l2 = tex_level(tex, w, h, d1 + 1, &lw, &lh); tex_bilinear(l2, lw, lh, s, t, c2);
+  for (int k = 0; k < 4; ++k) o[k] = c1[k] * (1.0f - fr) + c2[k] * fr;
 }
 
 void ref_gbuffer_clear(ref_gbuffer* g) {
@@ -229,6 +277,33 @@ void ref_raster_draw(const ref_draw* d, ref_gbuffer* g) {
       float vp[3], vn[3], uv[2], vc[3];
       for (int k = 0; k < 3; ++k) { vp[k] = INTERP(v[0].vp[k], v[1].vp[k], v[2].vp[k]); vn[k] = INTERP(v[0].vn[k], v[1].vn[k], v[2].vn[k]); vc[k] = INTERP(v[0].col[k], v[1].col[k], v[2].col[k]); }
       for (int k = 0; k < 2; ++k) uv[k] = INTERP(v[0].uv[k], v[1].uv[k], v[2].uv[k]);
+      /* screen-space derivatives of uv for the mip level: the SAME triangle's perspective-correct uv one pixel to the right and
+         one pixel down (forward differences of the exact attribute plane; GL hardware differences the quad's four invocations) */
+      float rho2 = 0.0f;
+      if (d->diffuse_tex && d->diffuse_levels >= 2) {
+        float duv[2][2];
+        for (int ax = 0; ax < 2; ++ax) {
+          const int xx = x + (ax == 0), yy = y + (ax == 1);
+          float g0, g1, g2;
+          if (!homog) {
+            const int qx = xx * 16 + 8, qy = yy * 16 + 8;
+            const int64_t u0 = sgn * edge(fx[1], fy[1], fx[2], fy[2], qx, qy);
+            const int64_t u1 = sgn * edge(fx[2], fy[2], fx[0], fy[0], qx, qy);
+            const int64_t u2 = sgn * edge(fx[0], fy[0], fx[1], fy[1], qx, qy);
+            g0 = ((float)u0 / farea) * iw[0]; g1 = ((float)u1 / farea) * iw[1]; g2 = ((float)u2 / farea) * iw[2];
+          } else {
+            const float X = (((float)xx + 0.5f) / (float)W) * 2.0f - 1.0f;
+            const float Y = 1.0f - (((float)yy + 0.5f) / (float)H) * 2.0f;
+            g0 = (E[0] * X + E[1] * Y) + E[2]; g1 = (E[3] * X + E[4] * Y) + E[5]; g2 = (E[6] * X + E[7] * Y) + E[8];
+          }
+          const float gs = (g0 + g1) + g2;
+          for (int k = 0; k < 2; ++k) duv[ax][k] = (((v[0].uv[k] * g0 + v[1].uv[k] * g1) + v[2].uv[k] * g2) / gs) - uv[k];
+        }
+        const float ux = duv[0][0] * (float)d->diffuse_w, vx = duv[0][1] * (float)d->diffuse_h;
+        const float uy = duv[1][0] * (float)d->diffuse_w, vy = duv[1][1] * (float)d->diffuse_h;
+        const float rx = ux * ux + vx * vx, ry = uy * uy + vy * vy;
+        rho2 = rx > ry ? rx : ry;
+      }
       /* ---------------- fragment shader (frag.glsl:100-257) ---------------- */
       float outNoise[4] = {0, 0, 0, 0};
       if (d->noise_tex) {
@@ -288,8 +363,11 @@ void ref_raster_draw(const ref_draw* d, ref_gbuffer* g) {
           if (d->has_vertex_color) { outColor[0] = vc[0]; outColor[1] = vc[1]; outColor[2] = vc[2]; outColor[3] = 1.0f; }
           else { outColor[0] = outColor[1] = outColor[2] = outColor[3] = 0.0f; }
         } else {
-          const int tx = nearest_index(uv[0], d->diffuse_w), ty = nearest_index(uv[1], d->diffuse_h);
-          for (int k = 0; k < 4; ++k) outColor[k] = d->diffuse_tex[((size_t)ty * d->diffuse_w + tx) * 4 + k];
+          if (d->diffuse_levels >= 2) tex_trilinear(d->diffuse_tex, d->diffuse_w, d->diffuse_h, d->diffuse_levels, uv[0], uv[1], rho2, outColor);
+          else {
+            const int tx = nearest_index(uv[0], d->diffuse_w), ty = nearest_index(uv[1], d->diffuse_h);
+            for (int k = 0; k < 4; ++k) outColor[k] = d->diffuse_tex[((size_t)ty * d->diffuse_w + tx) * 4 + k];
+          }
         }
       } else if (d->render_mode == 2) { outColor[0] = outColor[1] = outColor[2] = outColor[3] = 0.0f; }
       else {
@@ -301,8 +379,11 @@ void ref_raster_draw(const ref_draw* d, ref_gbuffer* g) {
           if (d->has_vertex_color) { outColor[0] = vc[0]; outColor[1] = vc[1]; outColor[2] = vc[2]; outColor[3] = 1.0f; }
           else { outColor[0] = 1.0f; outColor[1] = 0.0f; outColor[2] = 1.0f; outColor[3] = 1.0f; }
         } else {
-          const int tx = nearest_index(uv[0], d->diffuse_w), ty = nearest_index(uv[1], d->diffuse_h);
-          for (int k = 0; k < 4; ++k) outColor[k] = d->diffuse_tex[((size_t)ty * d->diffuse_w + tx) * 4 + k];
+          if (d->diffuse_levels >= 2) tex_trilinear(d->diffuse_tex, d->diffuse_w, d->diffuse_h, d->diffuse_levels, uv[0], uv[1], rho2, outColor);
+          else {
+            const int tx = nearest_index(uv[0], d->diffuse_w), ty = nearest_index(uv[1], d->diffuse_h);
+            for (int k = 0; k < 4; ++k) outColor[k] = d->diffuse_tex[((size_t)ty * d->diffuse_w + tx) * 4 + k];
+          }
         }
       }
       float outCanny = (n[2] < CANNY_THRESHOLD && n[2] > 0.0f) ? 1.0f : 0.0f;

@@ -16,7 +16,7 @@ class RefDraw(C.Structure):
                 ("has_vertex_color", i32), ("depth_test", i32), ("cull_back", i32), ("id_w", i32), ("id_h", i32),
                 ("noise_tex", vp), ("noise_w", i32), ("noise_h", i32), ("diffuse_tex", vp), ("diffuse_w", i32),
                 ("diffuse_h", i32), ("corrmap_tex", vp), ("corr_w", i32), ("corr_h", i32),
-                ("tangent", vp), ("bitangent", vp), ("normal_tex", vp), ("normal_w", i32), ("normal_h", i32)]
+                ("tangent", vp), ("bitangent", vp), ("normal_tex", vp), ("normal_w", i32), ("normal_h", i32), ("diffuse_levels", i32)]
 
 
 class RefGBuffer(C.Structure):
@@ -61,8 +61,9 @@ class GBufferRef:
     def clear(self):
         lib().ref_gbuffer_clear(C.byref(self.c))
 
-    def draw(self, task, uniforms, noise_tex=None, diffuse_tex=None, corrmap_tex=None, corr_hw=(0, 0), normal_tex=None):
-        """task: stable_renderer_amd.scene.DrawTask (host numpy mesh); uniforms: scene.draw_params(...)"""
+    def draw(self, task, uniforms, noise_tex=None, diffuse_tex=None, corrmap_tex=None, corr_hw=(0, 0), normal_tex=None, diffuse_mips=None):
+        """task: stable_renderer_amd.scene.DrawTask (host numpy mesh); uniforms: scene.draw_params(...).
+        diffuse_mips: (flat float32 chain, levels) from scene.build_mip_chain(diffuse_tex) -> the diffuse texture is sampled trilinear"""
         m = task.mesh
         d = RefDraw()
         keep = [m.positions, m.normals, m.uvs, m.tris, m.colors, m.vertex_ids, noise_tex, diffuse_tex, corrmap_tex]
@@ -77,6 +78,9 @@ class GBufferRef:
             d.noise_tex, d.noise_h, d.noise_w = _np(noise_tex), noise_tex.shape[0], noise_tex.shape[1]
         if diffuse_tex is not None:
             d.diffuse_tex, d.diffuse_h, d.diffuse_w = _np(diffuse_tex), diffuse_tex.shape[0], diffuse_tex.shape[1]
+            if diffuse_mips is not None:
+                keep.append(diffuse_mips[0])
+                d.diffuse_tex, d.diffuse_levels = _np(diffuse_mips[0]), int(diffuse_mips[1])
         if corrmap_tex is not None:
             d.corrmap_tex, d.corr_h, d.corr_w = _np(corrmap_tex), corr_hw[0], corr_hw[1]
         if normal_tex is not None:                      # (H, W, 4) float32; the mesh must carry tangents (Mesh.compute_tangents)

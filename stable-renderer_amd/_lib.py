@@ -78,7 +78,7 @@ class Draw(C.Structure):
                 ("has_vertex_color", i32), ("depth_test", i32), ("cull_back", i32), ("id_w", i32), ("id_h", i32),
                 ("noise_tex", vp), ("noise_w", i32), ("noise_h", i32), ("diffuse_tex", vp), ("diffuse_w", i32),
                 ("diffuse_h", i32), ("corrmap_tex", vp), ("corr_w", i32), ("corr_h", i32),
-                ("tangent", vp), ("bitangent", vp), ("normal_tex", vp), ("normal_w", i32), ("normal_h", i32)]
+                ("tangent", vp), ("bitangent", vp), ("normal_tex", vp), ("normal_w", i32), ("normal_h", i32), ("diffuse_levels", i32)]
 
 
 class GBuffer(C.Structure):

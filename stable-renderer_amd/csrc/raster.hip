@@ -87,6 +87,52 @@ __device__ __forceinline__ int nearest_index(float t, int n) {
   if (i < 0) i = 0;
   return i;
 }
+// ---- trilinear sampling of a mip-mapped RGBA32F texture (sr_draw.diffuse_levels >= 2): statement for statement
+// oracle/raster_ref.c tex_trilinear (OpenGL 4.6 section 8.14 in fp32 with a fixed operation order; lambda from the exponent of
+// rho^2 and a cubic for the mantissa, so that C and HIP produce the same bits)
+__device__ __forceinline__ int tex_wrap(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+__device__ __forceinline__ void tex_bilinear(const float* lvl, int w, int h, float s, float t, float* o) {
+  const float u = s * (float)w - 0.5f, v = t * (float)h - 0.5f;
+  const float fu = floorf(u), fv = floorf(v);
+  const float a = u - fu, b = v - fv;
+  const int i0 = tex_wrap((int)fu, w), i1 = tex_wrap(i0 + 1, w), j0 = tex_wrap((int)fv, h), j1 = tex_wrap(j0 + 1, h);
+  const float4 t00 = ((const float4*)lvl)[(size_t)j0 * w + i0], t10 = ((const float4*)lvl)[(size_t)j0 * w + i1];
+  const float4 t01 = ((const float4*)lvl)[(size_t)j1 * w + i0], t11 = ((const float4*)lvl)[(size_t)j1 * w + i1];
+  const float c00[4] = {t00.x, t00.y, t00.z, t00.w}, c10[4] = {t10.x, t10.y, t10.z, t10.w};
+  const float c01[4] = {t01.x, t01.y, t01.z, t01.w}, c11[4] = {t11.x, t11.y, t11.z, t11.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float top = c00[k] * (1.0f - a) + c10[k] * a, bot = c01[k] * (1.0f - a) + c11[k] * a;
+    o[k] = top * (1.0f - b) + bot * b;
+  }
+}
+__device__ __forceinline__ const float* tex_level(const float* tex, int w, int h, int level, int* lw, int* lh) {
+  size_t off = 0;
+  for (int k = 0; k < level; ++k) { off += (size_t)w * h * 4; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; }
+  *lw = w; *lh = h;
+  return tex + off;
+}
+__device__ __noinline__ void tex_trilinear(const float* tex, int w, int h, int levels, float s, float t, float rho2, float* o) {
+  int lw, lh;
+  s = s - floorf(s); t = t - floorf(t);
+  if (!(rho2 > 1.0f) || levels <= 1) { tex_bilinear(tex, w, h, s, t, o); return; }       // magnification (and NaN): level 0
+  unsigned bits = __float_as_uint(rho2);
+  const int e = (int)(bits >> 23) - 127;
+  bits = (bits & 0x7fffffu) | 0x3f800000u;
+  const float m = __uint_as_float(bits);
+  const float z = m - 1.0f;
+  const float l2m = z * (1.4380732774734497f + z * (-0.6747666597366333f + z * (0.31700071692466736f + z * -0.08030730485916138f)));
+  const float lam = 0.5f * ((float)e + l2m);
+  const int maxl = levels - 1;
+  if (!(lam < (float)maxl)) { const float* l = tex_level(tex, w, h, maxl, &lw, &lh); tex_bilinear(l, lw, lh, s, t, o); return; }
+  const int d1 = (int)lam;
+  const float fr = lam - (float)d1;
+  float c1[4], c2[4];
+  const float* l1 = tex_level(tex, w, h, d1, &lw, &lh); tex_bilinear(l1, lw, lh, s, t, c1);
+  const float* l2 = tex_level(tex, w, h, d1 + 1, &lw, &lh); tex_bilinear(l2, lw, lh, s, t, c2);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = c1[k] * (1.0f - fr) + c2[k] * fr;
+}
 __device__ __forceinline__ int to_fixed(float v) { return (int)floorf(v * 16.0f + 0.5f); }
 __device__ __forceinline__ long long edge_fn(int ax, int ay, int bx, int by, int px, int py) {
   return (long long)(bx - ax) * (long long)(py - ay) - (long long)(by - ay) * (long long)(px - ax);
@@ -174,6 +220,9 @@ __global__ void raster_setup(const sr_draw d, TriRec* __restrict__ recs, int W, 
   ((int4*)(recs + d.nt))[t] = r.valid ? make_int4(r.x0, r.x1, r.y0, r.y1) : make_int4(0x7fffffff, -1, 0x7fffffff, -1);
 }
 
+// TRILINEAR: the instantiation for a mip-mapped diffuse texture (sr_draw.diffuse_levels >= 2): uv derivatives + tex_trilinear cost
+// 30 more VGPRs, which the common instantiation (3 waves per SIMD at 170) must not pay
+template <bool TRILINEAR>
 __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gbuffer g, const TriRec* __restrict__ recs) {
   __shared__ TriRec srec[STAGE];
   __shared__ int sbin[BIN_CH * 256];
@@ -294,6 +343,37 @@ __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gb
 #pragma unroll
           for (int k = 0; k < 2; ++k) uv[k] = INTERP(T.uv[k], T.uv[2 + k], T.uv[4 + k]);
 #undef INTERP
+          // screen-space derivatives of uv for the mip level (oracle/raster_ref.c: the same triangle's perspective-correct uv one
+          // pixel right and one pixel down); only for a mip-mapped diffuse texture
+          float rho2 = 0.0f;
+          if constexpr (TRILINEAR) {
+            float duv[2][2];
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+              const int xx = x + (ax == 0), yy = y + (ax == 1);
+              float g0, g1, g2;
+              if (T.valid != 2) {
+                const int qx = xx * 16 + 8, qy = yy * 16 + 8;
+                const long long u0 = (long long)T.sgn * edge_fn(T.fx[1], T.fy[1], T.fx[2], T.fy[2], qx, qy);
+                const long long u1 = (long long)T.sgn * edge_fn(T.fx[2], T.fy[2], T.fx[0], T.fy[0], qx, qy);
+                const long long u2 = (long long)T.sgn * edge_fn(T.fx[0], T.fy[0], T.fx[1], T.fy[1], qx, qy);
+                g0 = ((float)u0 / T.farea) * T.iw[0]; g1 = ((float)u1 / T.farea) * T.iw[1]; g2 = ((float)u2 / T.farea) * T.iw[2];
+              } else {
+                const float X = (((float)xx + 0.5f) / (float)W) * 2.0f - 1.0f;
+                const float Y = 1.0f - (((float)yy + 0.5f) / (float)H) * 2.0f;
+                g0 = (__int_as_float(T.fx[0]) * X + __int_as_float(T.fx[1]) * Y) + __int_as_float(T.fx[2]);
+                g1 = (__int_as_float(T.fy[0]) * X + __int_as_float(T.fy[1]) * Y) + __int_as_float(T.fy[2]);
+                g2 = (T.z[0] * X + T.z[1] * Y) + T.z[2];
+              }
+              const float gs = (g0 + g1) + g2;
+#pragma unroll
+              for (int k = 0; k < 2; ++k) duv[ax][k] = (((T.uv[k] * g0 + T.uv[2 + k] * g1) + T.uv[4 + k] * g2) / gs) - uv[k];
+            }
+            const float ux = duv[0][0] * (float)d.diffuse_w, vx = duv[0][1] * (float)d.diffuse_h;
+            const float uy = duv[1][0] * (float)d.diffuse_w, vy = duv[1][1] * (float)d.diffuse_h;
+            const float rx = ux * ux + vx * vx, ry = uy * uy + vy * vy;
+            rho2 = rx > ry ? rx : ry;
+          }
           // ---------------- fragment shader ----------------
           float outNoise[4] = {0.f, 0.f, 0.f, 0.f};
           if (d.noise_tex) {
@@ -357,6 +437,7 @@ __global__ __launch_bounds__(256) void raster_tiles(const sr_draw d, const sr_gb
           }
           float outColor[4];
           auto sample_diffuse = [&]() {
+            if constexpr (TRILINEAR) { tex_trilinear((const float*)d.diffuse_tex, d.diffuse_w, d.diffuse_h, d.diffuse_levels, uv[0], uv[1], rho2, outColor); return; }
             const int tx = nearest_index(uv[0], d.diffuse_w), ty = nearest_index(uv[1], d.diffuse_h);
             const float4 t4 = ((const float4*)d.diffuse_tex)[(size_t)ty * d.diffuse_w + tx];
             outColor[0] = t4.x; outColor[1] = t4.y; outColor[2] = t4.z; outColor[3] = t4.w;
@@ -544,7 +625,10 @@ extern "C" int sr_raster_draw(const sr_draw* d, const sr_gbuffer* g, void* scrat
   TriRec* recs = (TriRec*)scratch;
   hipLaunchKernelGGL(raster_setup, dim3((d->nt + 255) / 256), dim3(256), 0, st, *d, recs, g->W, g->H);
   const int tiles = ((g->W + TILE - 1) / TILE) * ((g->H + TILE - 1) / TILE);
-  hipLaunchKernelGGL(raster_tiles, dim3(tiles), dim3(256), 0, st, *d, *g, recs);
+  if (d->diffuse_tex && d->diffuse_levels >= 2) {
+    if (d->diffuse_levels > 31 || d->diffuse_w <= 0 || d->diffuse_h <= 0) SR_FAIL(SR_ERR_INVALID, "sr_raster_draw: diffuse mip chain");
+    hipLaunchKernelGGL(raster_tiles<true>, dim3(tiles), dim3(256), 0, st, *d, *g, recs);
+  } else hipLaunchKernelGGL(raster_tiles<false>, dim3(tiles), dim3(256), 0, st, *d, *g, recs);
   SR_CHECK_LAUNCH("sr_raster_draw");
   return SR_OK;
 }

@@ -341,8 +341,9 @@ class SpriteInfo(Component):
 # ---- static resources: textures, materials ----------------------------------------------------------------------------------------
 class Texture:
     """static/texture/texture.py.  A texture here is an HBM tensor ``data`` (H, W, 4): row 0 = v in [0, 1/H) (GL's bottom row --
-    ``Load`` flips the image as the reference does, :421-431).  The rasterizer samples NEAREST with REPEAT (the only filtering that
-    is reproducible); filter / wrap arguments are recorded, not acted on."""
+    ``Load`` flips the image as the reference does, :421-431).  Wrap is REPEAT.  A diffuse texture whose min filter is a LINEAR
+    mip-map mode (the default, as in the reference) is sampled TRILINEAR by the rasterizer (scene.build_mip_chain,
+    sr_draw.diffuse_levels; anisotropy not restated); noise, id and corr-map lookups are NEAREST in the reference and here."""
 
     def __init__(self, name=None, width=None, height=None, format=TextureFormat.RGB, data_type=None, data=None,
                  min_filter=TextureFilter.LINEAR_MIPMAP_LINEAR, mag_filter=TextureFilter.LINEAR, s_wrap=TextureWrap.REPEAT,
@@ -446,6 +447,15 @@ class Material:
             return t.data
         return t if isinstance(t, torch.Tensor) else None
 
+    def filter_of(self, kind):
+        """-> 'trilinear' for a Texture whose min filter is a LINEAR mip-map mode (the reference's default, texture.py:57-60: file
+        textures are sampled GL_LINEAR_MIPMAP_LINEAR / GL_LINEAR), 'nearest' for NEAREST textures and bare tensors"""
+        t = self.textures.get(kind)
+        if isinstance(t, Texture) and t.min_filter in (TextureFilter.LINEAR, TextureFilter.LINEAR_MIPMAP_NEAREST,
+                                                       TextureFilter.NEAREST_MIPMAP_LINEAR, TextureFilter.LINEAR_MIPMAP_LINEAR):
+            return "trilinear"
+        return "nearest"
+
 
 class Material_MTL(Material):
     """static/material/material_MTL.py:13-110: one material per ``newmtl`` block; ``map_Kd`` / ``map_bump`` textures are looked up
@@ -536,6 +546,7 @@ class MeshRenderer(Component):
                 continue
             out.append(S.DrawTask(mesh, self.gameObj.transform.matrix, sprite_id=sid or 0, material_id=m.materialID,
                                   render_mode=RenderMode.NORMAL, diffuse_tex=m.tensor_of(DefaultTextureType.DiffuseTex),
+                                  diffuse_filter=m.filter_of(DefaultTextureType.DiffuseTex),
                                   noise_tex=m.tensor_of(DefaultTextureType.NoiseTex),
                                   normal_tex=m.tensor_of(DefaultTextureType.NormalTex),
                                   use_texcoord_id=bool(self.use_texcoord_id and mesh.has_uvs),

@@ -267,12 +267,39 @@ class RenderOrder:
     OPAQUE, TRANSPARENT, OVERLAY = 1000, 2000, 3000
 
 
+def build_mip_chain(tex):
+    """(H, W, 4) float32 image -> (flat float32 array: level 0 followed by its mip levels, number of levels).  Level k + 1 is the
+    2x2 box filter of level k, size max(1, w >> 1) x max(1, h >> 1) (an odd last row / column is dropped), down to 1 x 1 -- what
+    glGenerateMipmap produces for the reference's file textures (engine/static/texture/texture.py:276-289).  Summation order fixed:
+    ((a + b) + (c + d)) * 0.25 in fp32."""
+    lvl = np.ascontiguousarray(np.asarray(tex, dtype=F))
+    if lvl.ndim != 3 or lvl.shape[-1] != 4:
+        raise ValueError("texture must be (H, W, 4)")
+    out = [lvl.reshape(-1)]
+    while lvl.shape[0] > 1 or lvl.shape[1] > 1:
+        h, w = lvl.shape[:2]
+        h2, w2 = max(h >> 1, 1), max(w >> 1, 1)
+        y0 = np.arange(h2) * 2 if h > 1 else np.zeros(1, int)     # (a dimension that is already 1 texel is averaged with itself)
+        x0 = np.arange(w2) * 2 if w > 1 else np.zeros(1, int)
+        y1, x1 = (y0 + 1 if h > 1 else y0), (x0 + 1 if w > 1 else x0)
+        a, b = lvl[y0][:, x0], lvl[y0][:, x1]
+        c, d = lvl[y1][:, x0], lvl[y1][:, x1]
+        lvl = (((a + b) + (c + d)) * F(0.25)).astype(F)
+        out.append(lvl.reshape(-1))
+    return np.concatenate(out), len(out)
+
+
 class DrawTask:
-    """One (mesh x material) G-buffer task.  render_mode: 0 NORMAL, 1 BAKED, 2 BAKING (engine/static/enums.py:174-238)."""
+    """One (mesh x material) G-buffer task.  render_mode: 0 NORMAL, 1 BAKED, 2 BAKING (engine/static/enums.py:174-238).
+    diffuse_filter: "nearest" (one level) or "trilinear" (mip chain built on first use; the reference's default for file textures,
+    engine/static/texture/texture.py:57-60) -- colour plane only, ids / noise / corr-map lookups are NEAREST in the reference too."""
 
     def __init__(self, mesh, model, sprite_id=1, material_id=1, render_mode=0, corrmap_k=3, use_texcoord_id=False,
                  id_size=(512, 512), noise_tex=None, diffuse_tex=None, corrmap=None, order=RenderOrder.OPAQUE,
-                 has_vertex_color=False, normal_tex=None):
+                 has_vertex_color=False, normal_tex=None, diffuse_filter="nearest"):
+        if diffuse_filter not in ("nearest", "trilinear"):
+            raise ValueError("diffuse_filter must be 'nearest' or 'trilinear'")
+        self.diffuse_filter = diffuse_filter
         self.mesh, self.model = mesh, np.asarray(model, F)
         self.sprite_id, self.material_id, self.render_mode, self.corrmap_k = sprite_id, material_id, render_mode, corrmap_k
         self.use_texcoord_id, self.id_size = use_texcoord_id, id_size
@@ -346,6 +373,12 @@ class GBuffer:
             d.noise_tex, d.noise_h, d.noise_w = O._p(ntex), ntex.shape[0], ntex.shape[1]
         if dtex is not None:
             d.diffuse_tex, d.diffuse_h, d.diffuse_w = O._p(dtex), dtex.shape[0], dtex.shape[1]
+            if task.diffuse_filter == "trilinear":
+                cache = task.__dict__.setdefault("_dev_tex", {})
+                if "diffuse_mips" not in cache or cache["diffuse_mips"][0] is not task.diffuse_tex:
+                    chain, levels = build_mip_chain(task.diffuse_tex.detach().float().cpu().numpy())
+                    cache["diffuse_mips"] = (task.diffuse_tex, torch.from_numpy(chain).to(dev), levels)
+                d.diffuse_tex, d.diffuse_levels = O._p(cache["diffuse_mips"][1]), cache["diffuse_mips"][2]
         if task.corrmap is not None:
             d.corrmap_tex, d.corr_h, d.corr_w = O._p(task.corrmap._values), task.corrmap.height, task.corrmap.width
         need = L.lib().sr_raster_scratch_bytes(d.nt, self.W, self.H)

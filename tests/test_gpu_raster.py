@@ -285,3 +285,60 @@ def test_near_plane_crossing_triangles_bit_exact():
     assert np.array_equal(gb.normal_depth.cpu().numpy().view(np.uint16), ref.normal_depth)
     assert np.array_equal(gb.pos.cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
     assert np.array_equal(gb.canny.cpu().numpy(), ref.canny)
+
+
+def _checker(n, cell=1):
+    yy, xx = np.mgrid[0:n, 0:n]
+    c = (((yy // cell) + (xx // cell)) & 1).astype(np.float32)
+    t = np.stack([c, 1.0 - c, 0.25 + 0.5 * c, np.ones_like(c)], -1)
+    return torch.from_numpy(np.ascontiguousarray(t))
+
+
+@pytest.mark.parametrize("case", ["minified", "magnified", "ground_through_near_plane", "non_power_of_two"])
+def test_trilinear_diffuse_texture_bit_exact_and_filtered(case):
+    """diffuse_filter='trilinear' (the reference's default for file textures: GL_LINEAR_MIPMAP_LINEAR, texture.py:57-60) --
+    the mip chain of scene.build_mip_chain sampled by raster_tiles<true> equals oracle/raster_ref.c tex_trilinear bit for bit
+    on every plane, for minification (levels > 0), magnification (bilinear on level 0), the homogeneous (near-plane) path and a
+    texture whose sizes are not powers of two; a one-texel checkerboard seen from afar comes out GREY (NEAREST gives 0 / 1)"""
+    from stable_renderer_amd import scene as S
+    import raster_ref as R
+    W, H = 256, 192
+    cam = S.Camera((0, 0.3, 3.2), (0, 0, 0))
+    sphere = S.Mesh.Sphere(24)
+    model = S.matmul(S.rotate_y(20.0), S.scale(1.1))
+    if case == "minified":
+        tex = _checker(256)
+    elif case == "magnified":
+        tex = torch.rand(6, 5, 4, generator=torch.Generator().manual_seed(2))
+    elif case == "non_power_of_two":
+        tex = torch.rand(37, 50, 4, generator=torch.Generator().manual_seed(4))
+    else:
+        from test_raster_clip import ground_scene
+        W, H = 320, 200
+        cam, sphere, model = ground_scene(W, H)                      # (a quad through the near plane and behind the eye)
+        tex = _checker(128, 2)
+    task = S.DrawTask(sphere, model, sprite_id=1, material_id=1, render_mode=0, diffuse_tex=tex, diffuse_filter="trilinear", order=999.5)
+    near = S.DrawTask(sphere, model, sprite_id=1, material_id=1, render_mode=0, diffuse_tex=tex, order=999.5)
+    gb, gn = S.GBuffer(W, H), S.GBuffer(W, H)
+    gb.render([task], cam)
+    gn.render([near], cam)
+    torch.cuda.synchronize()
+    ref = R.GBufferRef(W, H)
+    ref.clear()
+    ref.draw(task, S.draw_params(task, cam.view(), cam.projection(W / H)), diffuse_tex=tex.numpy(), diffuse_mips=S.build_mip_chain(tex.numpy()))
+    cov = ref.id[..., 0] != 0
+    assert cov.mean() > 0.1
+    assert np.array_equal(gb.id.cpu().numpy(), ref.id)
+    assert np.array_equal(gb.color.cpu().numpy().view(np.uint16), ref.color)
+    assert np.array_equal(gb.normal_depth.cpu().numpy().view(np.uint16), ref.normal_depth)
+    assert np.array_equal(gb.pos.cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
+    # only the colour plane depends on the filter
+    assert np.array_equal(gb.id.cpu().numpy(), gn.id.cpu().numpy()) and np.array_equal(gb.pos.cpu().numpy(), gn.pos.cpu().numpy())
+    col, coln = gb.color.float().cpu().numpy(), gn.color.float().cpu().numpy()
+    assert not np.array_equal(col, coln)
+    if case == "minified":                                          # ~1.5 texels per pixel and more: the checker averages out
+        red, redn = col[..., 0][cov], coln[..., 0][cov]
+        assert set(np.unique(redn)) <= {0.0, 1.0}
+        assert abs(red.mean() - 0.5) < 0.05 and red.std() < 0.5 * redn.std()
+    if case == "magnified":                                         # bilinear: values strictly between texel values appear
+        assert len(np.unique(col[..., 0][cov])) > 10 * len(np.unique(coln[..., 0][cov]))

@@ -116,3 +116,34 @@ def test_oracle_normal_and_depth_planes_match_reference_dump(gold, fr):
     g.draw(t, dict(MV=MV.reshape(-1), MV_IT=S.inverse_transpose(MV).reshape(-1), P=P.reshape(-1), depth_test=1))
     check_planes_against_reference_dump(d, fr, g.id[..., 0] != 0, g.normal_depth.view(np.float16).astype(np.float32))
     assert not g.noise.any() and not g.canny.any()        # no noise texture -> zeros (frag:102-103); no 80-degree normals in view
+
+
+def test_oracle_trilinear_sampler_properties():
+    """oracle/raster_ref.c tex_trilinear (no GPU): a constant texture stays constant at every level of detail, the mip chain ends in
+    the mean, and a textured quad seen face-on at one texel per pixel reproduces the texture (level 0, texel centres)"""
+    import numpy as np
+    import raster_ref as R
+    from stable_renderer_amd import scene as S
+    tex = np.full((16, 16, 4), 0.375, np.float32)
+    tex[..., 3] = 1.0                                       # opaque: no blend against the cleared target
+    chain, levels = S.build_mip_chain(tex)
+    assert levels == 5 and np.all(chain.reshape(-1, 4) == np.array([0.375, 0.375, 0.375, 1.0], np.float32))
+    rnd = np.random.RandomState(0).rand(16, 8, 4).astype(np.float32)
+    chain, levels = S.build_mip_chain(rnd)
+    assert levels == 5 and np.allclose(chain[-4:], rnd.reshape(-1, 4).mean(0), atol=1e-6)
+    W = H = 64
+    cam = S.Camera((0, 0, 2.0), (0, 0, 0))
+    for k, t in enumerate((tex, np.random.RandomState(1).rand(64, 64, 4).astype(np.float32))):
+        quad = S.Mesh.Plane(1)
+        quad.positions[:, [1, 2]] = quad.positions[:, [2, 1]]
+        quad.normals[:] = (0, 0, 1)
+        quad.cullback = False
+        task = S.DrawTask(quad, S.scale(1.0), render_mode=0, diffuse_tex=None, diffuse_filter="trilinear")
+        g = R.GBufferRef(W, H)
+        g.clear()
+        g.draw(task, S.draw_params(task, cam.view(), cam.projection(1.0)), diffuse_tex=t, diffuse_mips=S.build_mip_chain(t))
+        cov = g.id[..., 0] != 0
+        assert cov.any()
+        col = g.color.view(np.float16).astype(np.float32)
+        if k == 0:
+            assert np.all(col[cov][:, :3] == np.float32(0.375))
