@@ -91,6 +91,9 @@ def main():
                          "(strong scaling; the replica figure is measured after it and printed beside it as `replicas`); "
                          "replica (default on one GPU): every GPU bakes its own 8-view group (weak scaling, no collective)")
     ap.add_argument("--no-replicas-beside", action="store_true", help="shard mode: skip the replica measurement that follows it")
+    ap.add_argument("--shard-inflight", action="store_true",
+                    help="shard mode: --inflight K sharded calls in flight per rank, every slot with its own process group "
+                         "(opt-in: rehearsed with gloo and a one-rank RCCL group only)")
     ap.add_argument("--workload", default="sd15-512", choices=["sd15-512", "sdxl-1024"],
                     help="sd15-512: the configuration BASELINE.json's metric is quoted on (default); sdxl-1024: BASELINE config 5, "
                          "the SDXL base UNet (2.57 B parameters) at 1024x1024 through the same raster / overlap / K-V injection / "
@@ -154,7 +157,7 @@ def main():
     if a.roofline_only:                                       # no calls: just the UNet step plan (as a sampling run builds it)
         a.warmup, a.steps, a.no_cpu_baseline = 0, 0, True
         pipe.runner._load_ctx(pipe.runner._ensure_plan([min(3, 2 * a.views - 1)]))
-    inflight = max(1, a.inflight) if (shard is None and not a.roofline_only) else 1
+    inflight = max(1, a.inflight) if ((shard is None or a.shard_inflight) and not a.roofline_only) else 1
     if inflight > 1:
         from stable_renderer_amd.pipeline import InflightCalls
         fl = InflightCalls(pipe, inflight)

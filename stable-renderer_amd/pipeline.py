@@ -257,12 +257,19 @@ class FramePipeline:
     def spawn(self, slot):
         """a second pipeline over the SAME weights, scene and corr-map with its own plans / buffers (InflightCalls); built with
         split-K scratch number ``slot``"""
+        shard = None
         if self.shard is not None:
-            raise NotImplementedError("calls in flight together with a view-sharded group")
+            # calls in flight inside a view-sharded group: every slot gets its OWN process group (communicator), so the collectives
+            # of different calls never share an ordering domain; every rank must spawn its slots in the same order (new_group is
+            # collective).  Rehearsed with gloo (2 ranks) and in a one-rank RCCL group; not the default anywhere (bench.py
+            # --shard-inflight): with several communicators in flight RCCL relies on their kernels being co-schedulable
+            import torch.distributed as dist
+            from .parallel import ViewShard
+            shard = ViewShard(self.N_all, group=dist.new_group())
         with O.workspace_slot(slot):
             p = FramePipeline(self.unet, self.vae, self.scene, n_views=self.N_all, steps=self.steps, cfg=self.cfg,
                               sampler=self.sampler, scheduler=self.scheduler, corresponder=copy.copy(self.corresponder),
-                              use_graph=self.runner.use_graph, controls=self.controls, keep_planes=self.keep_planes)
+                              use_graph=self.runner.use_graph, controls=self.controls, keep_planes=self.keep_planes, shard=shard)
         p.bg_noise = self.bg_noise
         p.frame0 = self.frame0
         if getattr(self, "_prompt", None) is not None:
@@ -363,10 +370,13 @@ class FramePipeline:
                 if order is not None:
                     torch.cuda.current_stream().synchronize()       # the next call's update runs on another stream
         else:
-            frames = self.shard.gather_frames_to_rank0(images)                # 'first' priority = frame order
-            if self.shard.rank == 0:
-                ed_all = EngineData(frame_indices=list(range(self.N_all)), id_maps=self._ids_all, correspond_maps=ed.correspond_maps)
-                self.baker.finished(ed_all, frames)
+            with (contextlib.nullcontext() if order is None else order[0].turn("bake", order[1])):   # (call order on every rank alike)
+                frames = self.shard.gather_frames_to_rank0(images)            # 'first' priority = frame order
+                if self.shard.rank == 0:
+                    ed_all = EngineData(frame_indices=list(range(self.N_all)), id_maps=self._ids_all, correspond_maps=ed.correspond_maps)
+                    self.baker.finished(ed_all, frames)
+                if order is not None:
+                    torch.cuda.current_stream().synchronize()
         mark("corrmap_update", t)
         return images
 

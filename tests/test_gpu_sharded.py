@@ -221,16 +221,34 @@ def _pipe_body(rank, world):
             w0, w1 = c0._writtens.cpu(), c1._writtens.cpu()
             dv = (c0._values - c1._values).abs().max().item()
             same = (bool((w0 == w1).all()), int(w0.sum()), dv)
-        return (rank, err, same)
+        # two sharded calls in flight per rank (each slot its own process group) bake what the sharded loop bakes
+        from stable_renderer_amd.pipeline import InflightCalls
+
+        def bake(inflight):
+            pipe = build_sd15_pipeline(shard=ViewShard(4), **kw)
+            torch.manual_seed(9)
+            if inflight == 1:
+                for _ in range(3):
+                    pipe.call()
+            else:
+                InflightCalls(pipe, inflight).run(3)
+            torch.cuda.synchronize()
+            cm = pipe.scene.corrmap
+            return cm._values.clone(), cm._writtens.clone()
+        v1, w1 = bake(1)
+        v2, w2 = bake(2)
+        flight = (int(w1.sum()), bool(torch.equal(w1, w2)), bool(torch.equal(v1, v2)))
+        return (rank, err, same, flight)
 
 
 def test_two_rank_pipeline_shard_bakes_the_same_corrmap(two_ranks):
     """raster (own views) -> id all-gather -> sharded sampling -> decode -> frames to rank 0 -> ordered corr-map update"""
     res = [r["pipe"] for r in two_ranks]
-    for rank, err, same in res:
+    for rank, err, same, flight in res:
         assert err < 2e-4, (rank, err)
         if rank == 0:
             assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same      # fp16 store of fp32 frames that differ by GEMM batch shape
+            assert flight[0] > 0 and flight[1] and flight[2], flight          # calls in flight inside the shard == the sharded loop
 
 
 def _cn_body(rank, world):
@@ -319,15 +337,35 @@ def _rccl_body(rank, world):
     comm_graph = p2.runner.exposed_comm_ms()
     c0, c1 = p0.scene.corrmap, p2.scene.corrmap
     same = (bool((c0._writtens == c1._writtens).all()), int(c0._writtens.sum()), (c0._values - c1._values).abs().max().item())
-    return ((eager - base).abs().max().item(), (graph - eager).abs().max().item(), comm_eager, comm_graph, same)
+    # calls in flight INSIDE the sharded group (every slot its own communicator): 4 calls, 2 in flight == the sequential loop
+    from stable_renderer_amd.pipeline import InflightCalls
+
+    def bake(inflight):
+        pipe = build_sd15_pipeline(shard=ViewShard(4), use_graph=False, **kw)
+        torch.manual_seed(9)
+        if inflight == 1:
+            for _ in range(4):
+                pipe.call()
+        else:
+            fl = InflightCalls(pipe, inflight)
+            assert fl.pipes[1].shard is not None and fl.pipes[1].shard.group is not pipe.shard.group
+            fl.run(4)
+        torch.cuda.synchronize()
+        cm = pipe.scene.corrmap
+        return cm._values.clone(), cm._writtens.clone()
+    v1, w1 = bake(1)
+    v2, w2 = bake(2)
+    flight = (int(w1.sum()), bool(torch.equal(w1, w2)), bool(torch.equal(v1, v2)))
+    return ((eager - base).abs().max().item(), (graph - eager).abs().max().item(), comm_eager, comm_graph, same, flight)
 
 
 def test_sharded_path_runs_through_rccl_in_a_one_rank_group():
-    (err, err_g, comm_e, comm_g, same), = _run_ranks(_rccl_worker, 1, 26700 + (os.getpid() % 1000), timeout=600)
+    (err, err_g, comm_e, comm_g, same, flight), = _run_ranks(_rccl_worker, 1, 26700 + (os.getpid() % 1000), timeout=600)
     assert err < 2e-4, err
     assert err_g < 1e-5, err_g
     assert comm_e is not None and comm_g is not None and comm_e >= 0.0 and comm_g >= 0.0      # asynchronous waits were timed
     assert same[0] and same[1] > 0 and same[2] <= 2 ** -10, same
+    assert flight[0] > 0 and flight[1] and flight[2], flight      # two sharded calls in flight bake exactly what the loop bakes
 
 
 def test_two_ranks_conditioning_lists_with_overlap_match_single_process(two_ranks):
