@@ -156,7 +156,16 @@ def main():
             torch.cuda.synchronize()
     if a.roofline_only:                                       # no calls: just the UNet step plan (as a sampling run builds it)
         a.warmup, a.steps, a.no_cpu_baseline = 0, 0, True
-        pipe.runner._load_ctx(pipe.runner._ensure_plan([min(3, 2 * a.views - 1)]))
+        p_ = pipe.runner._ensure_plan([min(3, 2 * a.views - 1)])
+        pipe.runner._load_ctx(p_)
+        # real activations in every buffer the igemm replay reads: a mid-schedule latent through the WHOLE plan once (a replay over
+        # the zero-filled buffers of a fresh plan multiplies zeros: ~5 % faster at the clocks idle data lines allow -- 790 vs 755 TF/s)
+        p_["x"].copy_(torch.randn(p_["x"].shape, generator=torch.Generator().manual_seed(5)).to(p_["x"].device) * 0.8)
+        p_["t"].fill_(500.0)
+        for r_ in (p_.get("schedule") or [("run", p_["step"])]):
+            if r_[0] == "run":
+                r_[1].run()
+        torch.cuda.synchronize()
     inflight = max(1, a.inflight) if ((shard is None or a.shard_inflight) and not a.roofline_only) else 1
     if inflight > 1:
         from stable_renderer_amd.pipeline import InflightCalls

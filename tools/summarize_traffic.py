@@ -1,7 +1,7 @@
 """HBM-side traffic of the igemm family per UNet evaluation from the two PMC passes of tools/profile_round.sh (development tool).
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch; on gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes
 (MI355X_MICROARCH.md, HBM section): doubled here.  `bench.py --roofline-only` makes 7 replays of the igemm subset + 5 of the whole
-step plan = 12 evaluations' worth of igemm launches (the few extra launches of the same kernels in the prologue plan — cross-attention
+step plan + 1 run of the whole plan on a real latent beforehand = 13 evaluations' worth of igemm launches (the few extra launches of the same kernels in the prologue plan — cross-attention
 K/V and time-embedding GEMMs, run once per sampling run — are counted in: < 0.5 % of the bytes)."""
 import csv
 import glob
@@ -26,7 +26,7 @@ def total(kind):
 
 fetch_kb, nf = total("fetch")
 write_kb, nw = total("write")
-evals = 12 if nf else 0          # 7 replays of the igemm subset + 5 of the whole step plan (bench.py --roofline-only)
+evals = 13 if nf else 0          # 1 run of the whole plan on a real latent + 7 replays of the igemm subset + 5 of the whole step plan (bench.py --roofline-only)
 res = {"fetch_size_kb_sum": fetch_kb, "write_size_kb_sum": write_kb, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,
        "evaluations_in_pass": evals,
        "fetch_bytes_per_eval_corrected": None if not evals else 2.0 * fetch_kb * 1024 / evals,
