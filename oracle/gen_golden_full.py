@@ -163,7 +163,7 @@ def _sd15_names():
 
 
 # ---- the bench workload's shape: 8 overlapped views, 512^2, full SD1.5 UNet + VAE -------------------
-def sec_bench8():
+def sec_bench8(steps=3, name="full_bench8"):
     from stable_renderer_amd.pipeline import BakeBallScene
     attention_basic()
     t0 = time.time()
@@ -171,14 +171,20 @@ def sec_bench8():
     mp, ns, _ = ref_model(GG.SD15, 0)
     check_names(ns, _sd15_names())
     pos, neg = [[ctx(1), {}]], [[ctx(2), {}]]
-    s, inj = ref_sample(mp, noise, pos, neg, ids, 3, 8.0, "ddim", "normal", 1234, overlap=dict(ratio=0.5, stop=500, n_rand=1))
-    print("bench8: sampling %.0f s" % (time.time() - t0))
+    s, inj = ref_sample(mp, noise, pos, neg, ids, steps, 8.0, "ddim", "normal", 1234, overlap=dict(ratio=0.5, stop=500, n_rand=1))
+    print("%s: sampling %.0f s" % (name, time.time() - t0))
     img = ref_decode(s)
-    GG.save("full_bench8", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, img_sub=sub4(img),
-            inj=np.array(inj), meta=np.frombuffer(json.dumps(dict(views=8, steps=3, sampler="ddim", scheduler="normal", cfg=8.0,
+    GG.save(name, noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, img_sub=sub4(img),
+            inj=np.array(inj), meta=np.frombuffer(json.dumps(dict(views=8, steps=steps, sampler="ddim", scheduler="normal", cfg=8.0,
                                                                  rng_seed=1234, pos_seed=1, neg_seed=2, unet_seed=0, vae_seed=2,
                                                                  ratio=0.5, stop=500)).encode(), np.uint8))
-    print("bench8: %.0f s" % (time.time() - t0))
+    print("%s: %.0f s" % (name, time.time() - t0))
+
+
+def sec_bench8_20():
+    """the headline workload at its headline length (VERDICT r3 missing #3): 8 overlapped views x 20 ddim steps, B = 16
+    evaluations of the full SD1.5 UNet through the reference's stack (about an hour of container CPU, run once)"""
+    sec_bench8(steps=20, name="full_bench8_20")
 
 
 # ---- BASELINE config 2: bake_ball, 1 view, 20 steps (was: oracle run beside the GPU run, 84 s of the GPU suite) ----------
@@ -321,11 +327,11 @@ def sec_nrand2():
             samples=s, e2e_inj=np.array(inj), rng_seed=np.array(4242))
 
 
-SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, config4=sec_config4, bench8=sec_bench8,
+SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, config4=sec_config4, bench8=sec_bench8, bench8_20=sec_bench8_20,
                 config2=sec_config2, config3=sec_config3)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for s_ in (_ARGV or list(SECTIONS)):
+    for s_ in (_ARGV or [k for k in SECTIONS if k != "bench8_20"]):
         print("==", s_, flush=True)
         SECTIONS[s_]()

@@ -48,8 +48,8 @@ class _Done:
     """handle of a transfer that has already completed (gloo staging, one-rank groups)"""
     is_async = False
 
-    def __init__(self, result=None):
-        self.result = result
+    def __init__(self, result=None, cached=False):
+        self.result, self.cached = result, cached      # cached: `result` is a buffer the next gather of the same shape overwrites
 
     def wait(self):
         return True
@@ -59,8 +59,8 @@ class _Pending:
     """handle of a collective running on the process group's own stream; wait() orders the CURRENT stream after it"""
     is_async = True
 
-    def __init__(self, work, result=None):
-        self.work, self.result = work, result
+    def __init__(self, work, result=None, cached=False):
+        self.work, self.result, self.cached = work, result, cached
 
     def wait(self):
         self.work.wait()
@@ -114,15 +114,15 @@ class ViewShard:
         if full is None:
             full = self._full[key] = torch.empty((self.n_views,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
         if x_local.is_cuda:
-            return _Pending(dist.all_gather_into_tensor(full, x_local, group=self.group, async_op=True), full)
+            return _Pending(dist.all_gather_into_tensor(full, x_local, group=self.group, async_op=True), full, cached=True)
         dist.all_gather(list(full.split(self.n_local)), x_local, group=self.group)
-        return _Done(full)
+        return _Done(full, cached=True)
 
     def gather_latents(self, x_local):
         """blocking form of gather_latents_start (a fresh tensor: callers keep it, e.g. the id maps of a call)"""
         h = self.gather_latents_start(x_local)
         h.wait()
-        return h.result.clone() if (h.is_async and h.result is not x_local) else h.result
+        return h.result.clone() if h.cached else h.result
 
     def overlap_step(self, x_local, step_fn, handle=None):
         """step_fn(full) mutates the full (N,C,h,w) latent in place (OverlapIndex.step on GPUs); every rank computes the
