@@ -101,8 +101,25 @@ typedef struct {
   int32_t up_h, up_w;     /* with upsample = 1: output size of the fused nearest upsample when it is not exactly 2H x 2W (0 = x2);
                              src = floor(dst * in/out) as F.interpolate(mode="nearest"): odd-sized latents (conditioning areas)
                              where Upsample.forward targets the skip tensor's size (openaimodel.py:109-121)                      */
+  int32_t* split_counters;/* optional: SR_IGEMM_SPLIT_COUNTERS int32 tile counters, ZERO before the first launch that sees them and left
+                             zero by every launch (one array per workspace: launches that may overlap in time need their own).  With
+                             them a split-K launch finishes inside the GEMM kernel: a workgroup publishes its fp32 partial, counts
+                             itself in, and the LAST of a tile's S workgroups to arrive sums the S partials in fixed z order and runs
+                             the ordinary epilogue -- same bits whichever workgroup that is, no float atomics, nobody waits, and no
+                             second launch.  NULL: the partials are reduced by a separate kernel (two launches).                  */
+  int32_t group;          /* plans only (sr_plan_run / sr_plan_capture; sr_igemm ignores it): this op and the next group-1 ops are igemm
+                             ops that do not depend on each other (the Q, K and V^T projections of a transformer block; a ResBlock's
+                             skip convolution and its first 3x3 convolution) and are handed to sr_igemm_group together.  0 / 1 = alone */
+  int32_t reserved_;
 } sr_igemm_args;
+#define SR_IGEMM_SPLIT_COUNTERS 4096
+#define SR_IGEMM_GROUP_MAX 4
 int sr_igemm(const sr_igemm_args* args, void* stream);
+/* n <= SR_IGEMM_GROUP_MAX INDEPENDENT problems (no output of one is an input of another).  When they can share a kernel -- same
+ * dtype, the same pinned `tile` (2, 3, 4, 13, 14, 15; fp16 also 9, 10), split = -1, row-major outputs -- they run as ONE launch
+ * whose workgroups are divided among the problems: at small batches every such kernel is a latency chain on a fraction of the
+ * CUs, and kernels of one stream otherwise run strictly one after another.  Anything else is launched one by one: same results. */
+int sr_igemm_group(const sr_igemm_args* const* args, int32_t n, void* stream);
 
 /* GroupNorm(32 groups) [+SiLU] over NHWC, optional channel concat of two sources (th.cat([h, hsp]) in
  * UNetModel.forward, openaimodel.py:921).  Replaces GroupNorm32 + SiLU in ResBlock.in_layers/out_layers,

@@ -23,7 +23,7 @@ class IgemmArgs(C.Structure):
                 ("KH", i32), ("stride", i32), ("upsample", i32), ("act", i32), ("transpose_out", i32), ("ldt", i32),
                 ("out_f32", i32), ("dtype", i32), ("scale", f32), ("rowvec_ld", i32), ("workspace", vp),
                 ("workspace_bytes", C.c_int64), ("row_stats", vp), ("colsum", vp), ("tile", i32), ("split", i32), ("pad_br", i32),
-                ("prefetch", vp), ("prefetch_bytes", C.c_int64), ("up_h", i32), ("up_w", i32)]
+                ("prefetch", vp), ("prefetch_bytes", C.c_int64), ("up_h", i32), ("up_w", i32), ("split_counters", vp), ("group", i32), ("reserved_", i32)]
 
 
 class GroupNormArgs(C.Structure):
@@ -102,6 +102,7 @@ SYMBOLS = {
     "sr_unet_forward": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "sr_vae_decode": (C.c_int, [vp, vp, vp, vp]),
     "sr_igemm": (C.c_int, [P(IgemmArgs), vp]),
+    "sr_igemm_group": (C.c_int, [P(P(IgemmArgs)), i32, vp]),
     "sr_groupnorm": (C.c_int, [P(GroupNormArgs), vp]),
     "sr_groupnorm_scratch_floats": (i64, [i32, i32]),
     "sr_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i32, f32, i32, vp]),

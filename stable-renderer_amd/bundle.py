@@ -52,7 +52,7 @@ def export_bundle(path, plans, io, constants=()):
     pool = []
     for p in plans.values():
         pool += list(p._keep)
-    pool += [t for t, _ in io.values()] + list(constants) + list(O._WS.values()) + list(O._zero_pages.values())
+    pool += [t for t, _ in io.values()] + list(constants) + list(O._WS.values()) + list(O._WSC.values()) + list(O._zero_pages.values())
     regions = _storages(pool)
     starts = [r[0] for r in regions]
     const_ptrs = {t.untyped_storage().data_ptr() for t in constants if isinstance(t, torch.Tensor) and t.is_cuda}

@@ -355,9 +355,11 @@ __device__ __forceinline__ void wait_leaving(int y) {
 // BKB = bytes of K per LDS stage: 128 (two MFMA k-substeps, 8 rows x 8 chunks per LDS-DMA instruction) or 64 (one k-substep,
 // 16 rows x 4 chunks) -- the 64-byte form halves a stage so that the 256x320 tile gets a FOUR-deep ring in 144 KB (three
 // K-steps of loads in flight instead of one: that tile is otherwise bound by the exposed load latency of every K-step).
+// The kernel body: `bid` of `nblk` is the workgroup's index among the workgroups of THIS problem (blockIdx.x / gridDim.x for an
+// ordinary launch; a grouped launch runs several problems side by side, see igemm_group_kernel)
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
-                                                                        const int NT, const int nwg, const int tile0) {
+__device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, const int Ho, const int Wo,
+                                           const int NT, const int nwg, const int tile0, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
   // [256 B per wave: landing zone of the weight prefetch (sr_igemm_args.prefetch), never read] [bias / colsum rows] [ring]
   constexpr int PF_B = WAVES_M * WAVES_N * 256;
@@ -386,11 +388,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
 #endif
   SR_TS(0);
   if (p.prefetch) {
-    const int64_t nthr = (int64_t)gridDim.x * gridDim.y * (NW * 64);
-    sr_prefetch_touch(p.prefetch, p.prefetch_bytes, ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NW * 64) + tid, nthr,
+    const int64_t nthr = (int64_t)nblk * gridDim.y * (NW * 64);
+    sr_prefetch_touch(p.prefetch, p.prefetch_bytes, ((int64_t)blockIdx.y * nblk + bid) * (NW * 64) + tid, nthr,
                       __builtin_amdgcn_readfirstlane(sr_lds_addr(smem_all) + wv * 256));
   }
-  const int wg = tile0 + sr_xcd_remap(blockIdx.x, nwg);      // this launch covers tiles [tile0, tile0 + nwg)
+  const int wg = tile0 + sr_xcd_remap(bid, nwg);             // this launch covers tiles [tile0, tile0 + nwg)
   const int mt = wg / NT, nt = wg - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
   if constexpr (VECPRE) {
@@ -641,6 +643,39 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) ws[(tn * TM + tm) * 64] = acc[tn][tm];
+    if (p.split_counters == nullptr) return;                 // two-launch form: splitk_reduce_kernel finishes the tile
+    // ---- fix-up inside the GEMM (sr_igemm_args.split_counters): every workgroup publishes its partial (agent-scope release),
+    // counts itself in, and the LAST of the tile's gridDim.y workgroups to arrive sums all partials in z order -- its own is read
+    // back like the others, so the bits do not depend on who is last -- and runs the ordinary epilogue.  Nobody waits for anybody;
+    // the last arriver re-zeroes the counter for the next launch.  Saves the reduce launch (5-11 us each, 30 per B = 16 UNet
+    // evaluation, 67 at B = 2) and the partials' second trip through a cold kernel.
+    __threadfence();
+    __syncthreads();                                         // all partial stores of the workgroup are published; the ring is dead
+    int* const flag = (int*)smem_all;
+    if (tid == 0) {
+      const int prev = __hip_atomic_fetch_add(p.split_counters + (wg - tile0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = prev == (int)gridDim.y - 1;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    __threadfence();                                         // acquire: the other workgroups' partials
+    {
+      const f32x4* wr = (const f32x4*)p.workspace + ((int64_t)(wg - tile0) * NW + wv) * (TN * TM * 64) + lane;
+      const int64_t zs = (int64_t)nwg * NW * (TN * TM * 64);
+      const int S = gridDim.y;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = wr[(tn * TM + tm) * 64];
+      for (int z = 1; z < S; ++z) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) acc[tn][tm] += wr[z * zs + (tn * TM + tm) * 64];
+      }
+      if (tid == 0) p.split_counters[wg - tile0] = 0;
+    }
+    epilogue_rows<T, BM, BN, WAVES_M, WAVES_N, STAGES * STAGE_BYTES, true, (MINB >= 4 ? 128 : 256), VECPRE>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
     return;
   } else if constexpr (!TRANS) {
     epilogue_rows<T, BM, BN, WAVES_M, WAVES_N, STAGES * STAGE_BYTES, true, (MINB >= 4 ? 128 : 256), VECPRE>(p, acc, smem, M, rpb, m0, n0, pm0, qn0, wv, lane);
@@ -648,7 +683,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
     SR_TS(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SR_TS(5);
-    if (threadIdx.x == 0 && p.workspace && !SPLIT) { unsigned long long* w_ = (unsigned long long*)p.workspace + (size_t)blockIdx.x * 8; for (int k_ = 0; k_ < 6; ++k_) w_[k_] = ts_[k_]; w_[6] = __smid(); }
+    if (threadIdx.x == 0 && p.workspace && !SPLIT) { unsigned long long* w_ = (unsigned long long*)p.workspace + (size_t)bid * 8; for (int k_ = 0; k_ < 6; ++k_) w_[k_] = ts_[k_]; w_[6] = __smid(); }
 #endif
   } else {
     const bool vec = (rpb % 4 == 0) && (p.ldt % 4 == 0);
@@ -685,6 +720,61 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(con
       }
     }
   }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
+                                                                        const int NT, const int nwg, const int tile0) {
+  igemm_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, SPLIT, BKB, SPREAD, MINB>(p, M, Ho, Wo, NT, nwg, tile0, blockIdx.x, gridDim.x);
+}
+
+// Several INDEPENDENT problems in one launch (sr_igemm_group): the workgroups of problem i are the blocks [start[i], start[i+1]).
+// Why: at small batches (one view per GPU of a shard: B = 2) almost every UNet kernel is a latency chain on a fraction of the
+// CUs -- launch, first stage, a short K loop, epilogue -- and the kernels of one stream run strictly one after the other; two
+// parallel hipGraph branches cost more in fork / join than they return (measured: 6.62 vs 6.41 ms per B = 2 evaluation).  A block
+// range per problem gives the same concurrency inside ONE dispatch: Q, K and V^T projections of a transformer block (three launches
+// of 8-15 us each) run as one, a ResBlock's skip convolution beside its first 3x3 convolution.
+struct igemm_group_k {
+  sr_igemm_args p[SR_IGEMM_GROUP_MAX];
+  int M[SR_IGEMM_GROUP_MAX], Ho[SR_IGEMM_GROUP_MAX], Wo[SR_IGEMM_GROUP_MAX], NT[SR_IGEMM_GROUP_MAX], nwg[SR_IGEMM_GROUP_MAX];
+  int start[SR_IGEMM_GROUP_MAX + 1];
+  int n;
+};
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKB = 128, int SPREAD = 0, int MINB = 1>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_group_kernel(const igemm_group_k g) {
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < SR_IGEMM_GROUP_MAX; ++j) if (j < g.n && (int)blockIdx.x >= g.start[j]) i = j;
+  igemm_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, false, false, BKB, SPREAD, MINB>(g.p[i], g.M[i], g.Ho[i], g.Wo[i], g.NT[i], g.nwg[i], 0,
+                                                                                     (int)blockIdx.x - g.start[i], g.nwg[i]);
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKB = 128, int SPREAD = 0, int MINB = 1>
+int launch_group(const sr_igemm_args* const* as, const int* Ms, const int* Hos, const int* Wos, int n, hipStream_t st) {
+  igemm_group_k g;
+  g.n = n;
+  int tot = 0;
+  for (int i = 0; i < SR_IGEMM_GROUP_MAX; ++i) {
+    const int k = i < n ? i : n - 1;
+    g.p[i] = *as[k];
+    g.p[i].prefetch = nullptr;
+    g.M[i] = Ms[k]; g.Ho[i] = Hos[k]; g.Wo[i] = Wos[k];
+    g.NT[i] = (as[k]->N + BN - 1) / BN;
+    g.nwg[i] = ((Ms[k] + BM - 1) / BM) * g.NT[i];
+    g.start[i] = tot;
+    if (i < n) tot += g.nwg[i];
+  }
+  g.start[SR_IGEMM_GROUP_MAX] = tot;
+  constexpr int lds_stage = STAGES * (BM + BN) * BKB;
+  constexpr int lds_epi_all = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);
+  constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
+  constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0) + WAVES_M * WAVES_N * 256;
+  auto k = igemm_group_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, BKB, SPREAD, MINB>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  hipLaunchKernelGGL(k, dim3(tot), dim3(WAVES_M * WAVES_N * 64), lds, st, g);
+  SR_CHECK_LAUNCH("sr_igemm_group");
+  return SR_OK;
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, int SPREAD = 0, int MINB = 1>
@@ -784,9 +874,13 @@ int launch_split(const sr_igemm_args& a, int M, int Ho, int Wo, int tile0, int S
     attr_set = true;
   }
   if (tile0 > 0) hipLaunchKernelGGL(kf, dim3(tile0), dim3(256), lds, st, a, M, Ho, Wo, NTv, tile0, 0);
-  hipLaunchKernelGGL(ks, dim3(ntail, S), dim3(256), lds, st, a, M, Ho, Wo, NTv, ntail, tile0);
-  constexpr int FR = (BM / 32) * (BN / 32);
-  hipLaunchKernelGGL((splitk_reduce_kernel<T, BM, BN>), dim3(ntail * FR), dim3(256), 0, st, a, M, Ho * Wo, S, NTv, ntail, tile0);
+  sr_igemm_args as = a;
+  if (ntail > SR_IGEMM_SPLIT_COUNTERS) as.split_counters = nullptr;
+  hipLaunchKernelGGL(ks, dim3(ntail, S), dim3(256), lds, st, as, M, Ho, Wo, NTv, ntail, tile0);
+  if (!as.split_counters) {
+    constexpr int FR = (BM / 32) * (BN / 32);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T, BM, BN>), dim3(ntail * FR), dim3(256), 0, st, a, M, Ho * Wo, S, NTv, ntail, tile0);
+  }
   SR_CHECK_LAUNCH("sr_igemm(split-K)");
   return SR_OK;
 }
@@ -1131,7 +1225,8 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
+// argument checks shared by sr_igemm and sr_igemm_group; -> M, Ho, Wo of the GEMM view
+static int igemm_check(const sr_igemm_args* a, int* M_, int* Ho_, int* Wo_) {
   if (!a || !a->a || !a->w || !a->out || !a->zero_page) SR_FAIL(SR_ERR_INVALID, "sr_igemm: null pointer");
   const int ke = a->dtype == SR_F16 ? 64 : 32;
   if (a->dtype != SR_F16 && a->dtype != SR_F32) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad dtype %d", a->dtype);
@@ -1157,11 +1252,64 @@ extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
   else { Ho = a->H; Wo = a->W; }
   const int64_t M64 = (int64_t)a->B * Ho * Wo;
   if (M64 > 0x7fffffffLL / 2) SR_FAIL(SR_ERR_INVALID, "sr_igemm: M too large");
-  const int M = (int)M64;
   if (a->transpose_out && a->ldt < Ho * Wo) SR_FAIL(SR_ERR_INVALID, "sr_igemm: ldt < pixels per batch");
+  *M_ = (int)M64; *Ho_ = Ho; *Wo_ = Wo;
+  return SR_OK;
+}
+
+extern "C" int sr_igemm(const sr_igemm_args* a, void* stream) {
+  int M, Ho, Wo;
+  const int rc = igemm_check(a, &M, &Ho, &Wo);
+  if (rc != SR_OK) return rc;
   hipStream_t st = sr_stream(stream);
   if (a->dtype == SR_F16) {
     return a->transpose_out ? dispatch<_Float16, true>(*a, M, Ho, Wo, st) : dispatch<_Float16, false>(*a, M, Ho, Wo, st);
   }
   return a->transpose_out ? dispatch<float, true>(*a, M, Ho, Wo, st) : dispatch<float, false>(*a, M, Ho, Wo, st);
+}
+
+// tiles a grouped launch can run (the non-split 4-wave tiles and the two-per-CU 8-wave tiles): 0 = no
+template <typename T>
+static int group_launch(int tile, const sr_igemm_args* const* as, const int* Ms, const int* Hos, const int* Wos, int n, hipStream_t st) {
+  switch (tile) {
+    case 2: return launch_group<T, 128, 128, 2, 2, 2>(as, Ms, Hos, Wos, n, st);
+    case 3: return launch_group<T, 128, 64, 2, 2, 2>(as, Ms, Hos, Wos, n, st);
+    case 4: return launch_group<T, 64, 64, 2, 2, 2>(as, Ms, Hos, Wos, n, st);
+    case 13: return launch_group<T, 64, 64, 2, 2, 8>(as, Ms, Hos, Wos, n, st);
+    case 14: return launch_group<T, 128, 64, 2, 2, 6>(as, Ms, Hos, Wos, n, st);
+    case 15: return launch_group<T, 128, 128, 2, 2, 4>(as, Ms, Hos, Wos, n, st);
+    default: break;
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (tile == 9) return launch_group<T, 128, 160, 4, 2, 2, 128, 0, 4>(as, Ms, Hos, Wos, n, st);
+    if (tile == 10) return launch_group<T, 128, 320, 2, 4, 2, 64, 0, 4>(as, Ms, Hos, Wos, n, st);
+  }
+  return -100;
+}
+
+extern "C" int sr_igemm_group(const sr_igemm_args* const* args, int32_t n, void* stream) {
+  if (!args || n < 1 || n > SR_IGEMM_GROUP_MAX) SR_FAIL(SR_ERR_INVALID, "sr_igemm_group: 1..%d problems", SR_IGEMM_GROUP_MAX);
+  int M[SR_IGEMM_GROUP_MAX], Ho[SR_IGEMM_GROUP_MAX], Wo[SR_IGEMM_GROUP_MAX];
+  bool one = n > 1;
+  for (int i = 0; i < n; ++i) {
+    const int rc = igemm_check(args[i], &M[i], &Ho[i], &Wo[i]);
+    if (rc != SR_OK) return rc;
+    const sr_igemm_args* a = args[i];
+    // one launch needs one kernel: same dtype and pinned tile, row-major outputs, no split-K (its workspace and second grid
+    // dimension belong to a single problem), and a tile that is legal for every member's width
+    one = one && a->dtype == args[0]->dtype && a->tile == args[0]->tile && a->tile != 0 && !a->transpose_out && a->split == -1;
+    if (a->tile == 9) one = one && a->N % 160 == 0;
+    if (a->tile == 10) one = one && a->N % 320 == 0;
+  }
+  hipStream_t st = sr_stream(stream);
+  if (one) {
+    const int rc = args[0]->dtype == SR_F16 ? group_launch<_Float16>(args[0]->tile, args, M, Ho, Wo, n, st)
+                                            : group_launch<float>(args[0]->tile, args, M, Ho, Wo, n, st);
+    if (rc != -100) return rc;
+  }
+  for (int i = 0; i < n; ++i) {                               // not groupable as given: the same results, one launch each
+    const int rc = sr_igemm(args[i], stream);
+    if (rc != SR_OK) return rc;
+  }
+  return SR_OK;
 }

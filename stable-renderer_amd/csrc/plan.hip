@@ -79,7 +79,20 @@ extern "C" int sr_plan_run(const sr_op* ops, int32_t n, void* stream) {
       continue;
     }
     if (ops[i].lane == 1 && !side_open) SR_FAIL(SR_ERR_INVALID, "sr_plan_run: side-lane op %d outside FORK..JOIN", i);
-    const int rc = run_op(ops[i], ops[i].lane == 1 ? (void*)sd.s : stream);
+    int rc;
+    const int grp = ops[i].kind == SR_OP_IGEMM ? ops[i].u.igemm.group : 0;
+    if (grp > 1) {
+      // sr_igemm_args.group: this op and the next grp-1 are independent igemm ops -> one grouped launch (sr_igemm_group)
+      if (grp > SR_IGEMM_GROUP_MAX || i + grp > n) SR_FAIL(SR_ERR_INVALID, "sr_plan_run: op %d: group of %d", i, grp);
+      const sr_igemm_args* ptr[SR_IGEMM_GROUP_MAX];
+      for (int j = 0; j < grp; ++j) {
+        if (ops[i + j].kind != SR_OP_IGEMM || ops[i + j].lane != ops[i].lane) SR_FAIL(SR_ERR_INVALID, "sr_plan_run: op %d: group member %d is not an igemm op of the same lane", i, j);
+        ptr[j] = &ops[i + j].u.igemm;
+      }
+      rc = sr_igemm_group(ptr, grp, ops[i].lane == 1 ? (void*)sd.s : stream);
+      if (rc == SR_OK) { i += grp - 1; continue; }
+    } else
+      rc = run_op(ops[i], ops[i].lane == 1 ? (void*)sd.s : stream);
     if (rc != SR_OK) {
       char buf[400];
       snprintf(buf, sizeof(buf), "%s", sr_last_error());

@@ -86,6 +86,19 @@ def workspace(device, nbytes=64 << 20):
     return _WS[key]
 
 
+SPLIT_COUNTERS = 4096                                       # include/sr_hip.h: SR_IGEMM_SPLIT_COUNTERS
+_WSC = {}
+
+
+def split_counters(device):
+    """zeroed tile counters that travel with the split-K workspace of the same (device, in-flight slot): the last workgroup of a
+    split tile to arrive reduces it inside the GEMM kernel (sr_igemm_args.split_counters) and leaves its counter at zero"""
+    key = (str(device), getattr(_tls, "slot", 0))
+    if key not in _WSC:
+        _WSC[key] = torch.zeros(SPLIT_COUNTERS, dtype=torch.int32, device=device)
+    return _WSC[key]
+
+
 def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C2=0, bias=None, rowvec=None,
                residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0, tile=0, split=0, row_stats=None, colsum=None,
                pad_br=0, up_hw=None):
@@ -102,6 +115,13 @@ def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C
     ar.row_stats, ar.colsum = _p(row_stats), _p(colsum)
     ws = workspace(a.device)
     ar.workspace, ar.workspace_bytes = _p(ws), ws.numel()
+    # The in-GEMM fix-up of split-K (last workgroup of a tile reduces it: sr_igemm_args.split_counters) is parity-clean and
+    # bit-reproducible but OFF by default: publishing a partial needs an agent-scope release per workgroup, which on this part is a
+    # write-back of the XCD's whole L2 (buffer_wbl2) -- measured 1.5-3x SLOWER than partials + splitk_reduce_kernel wherever it
+    # applies (M 512 K 1280 N 1280 split 4: 57.5 vs 22.3 us; 8x8 C1280 3x3 split 12: 51.7 vs 26.5 us; growing with tiles x S).
+    # A kernel boundary does that write-back once for everybody.  SR_SPLIT_FIXUP=1 turns it on.
+    if os.environ.get("SR_SPLIT_FIXUP", "0") == "1":
+        ar.split_counters = _p(split_counters(a.device))
     return ar
 
 
@@ -211,8 +231,7 @@ def tune_igemm(ar, min_flops=2.0e8, reps=4, allow_split=True):
     flops = 2.0 * ar.B * Ho * Wo * ar.N * ar.KH * ar.KH * (ar.C1 + ar.C2)
     if flops < min_flops:
         return
-    sig = (ar.dtype, ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample, ar.act, ar.transpose_out, ar.out_f32,
-           bool(ar.residual), bool(ar.rowvec), bool(allow_split), bool(ar.row_stats), ar.pad_br, ar.up_h, ar.up_w)
+    sig = _sig(ar, allow_split)
     if sig not in _TUNED and _TUNE_COLD:
         _tune_cold(ar, sig, allow_split, reps)
     if sig not in _TUNED:                                    # SR_TUNE_COLD=0: back-to-back timing
@@ -263,6 +282,100 @@ def tune_igemm(ar, min_flops=2.0e8, reps=4, allow_split=True):
             print(f"[tune] B{ar.B} {ar.H}x{ar.W} C{ar.C1}+{ar.C2} N{ar.N} k{ar.KH} s{ar.stride} u{ar.upsample} act{ar.act} "
                   f"t{ar.transpose_out} -> tile {best[0]} split {best[1]}  {best_t * 1e3:.1f} us", flush=True)
     ar.tile, ar.split = _TUNED[sig]
+
+
+GROUP_TILES = (4, 13, 3, 14, 2, 15, 9, 10)                  # tiles sr_igemm_group can run as one launch (include/sr_hip.h)
+GROUP_MAX = 4
+
+
+def _sig(ar, allow_split=True):
+    return (ar.dtype, ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample, ar.act, ar.transpose_out, ar.out_f32,
+            bool(ar.residual), bool(ar.rowvec), bool(allow_split), bool(ar.row_stats), ar.pad_br, ar.up_h, ar.up_w)
+
+
+def igemm_group(ars, stream=None):
+    """independent igemm problems as one launch where possible (sr_igemm_group)"""
+    arr = (C.POINTER(L.IgemmArgs) * len(ars))(*[C.pointer(a) for a in ars])
+    L.check(L.lib().sr_igemm_group(arr, len(ars), stream_ptr() if stream is None else stream))
+
+
+def tune_group(ars, reps=4):
+    """ars: sr_igemm_args of INDEPENDENT ops that follow each other in a plan, each already tuned on its own.  Times them one after
+    another against ONE grouped launch under every tile the group kernel has (same cold-weights / warm-inputs state as the per-shape
+    tuner) and, when a grouped launch wins, pins that tile in all of them and marks the first with ``group = n`` (sr_plan_run then
+    hands them to sr_igemm_group).  -> True when grouped"""
+    n = len(ars)
+    if n < 2 or n > GROUP_MAX or not autotune_enabled() or os.environ.get("SR_IGEMM_GROUPS", "1") == "0":
+        return False
+    if any(a.transpose_out for a in ars) or len({a.dtype for a in ars}) != 1:
+        return False
+    key = (-7, n) + tuple(x for a in ars for x in _sig(a))
+    if key not in _TUNED:
+        lib, st = L.lib(), stream_ptr()
+        dev = torch.cuda.current_device()
+        if dev not in _FLUSH:
+            _FLUSH[dev] = torch.empty(320 << 20, dtype=torch.uint8, device="cuda")
+        flush = _FLUSH[dev]
+        warm = []
+        for ar in ars:
+            es = 2 if ar.dtype == L.SR_F16 else 4
+            warm.append((ar.a, ar.B * ar.H * ar.W * ar.C1 * es))
+            if ar.a2 and ar.C2:
+                warm.append((ar.a2, ar.B * ar.H * ar.W * ar.C2 * es))
+        arr = (C.POINTER(L.IgemmArgs) * n)(*[C.pointer(a) for a in ars])
+
+        def timed(fn, k):
+            tot = 0.0
+            for _ in range(k):
+                flush.add_(1)
+                for ptr, nbytes in warm:
+                    lib.sr_cache_touch(ptr, nbytes, st)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                tot += e0.elapsed_time(e1)
+            return tot / k
+        own = [(a.tile, a.split) for a in ars]
+
+        def seq():
+            for a in ars:
+                lib.sr_igemm(C.byref(a), st)
+        seq()
+        t_seq = min(timed(seq, reps), timed(seq, reps))
+        times = {}
+        for t in GROUP_TILES:
+            if (t == 9 and any(a.N % 160 for a in ars)) or (t == 10 and any(a.N % 320 for a in ars)) or (t in (9, 10) and ars[0].dtype != L.SR_F16):
+                continue
+            for a in ars:
+                a.tile, a.split = t, -1
+            if lib.sr_igemm_group(arr, n, st) != 0:
+                continue
+            times[t] = timed(lambda: lib.sr_igemm_group(arr, n, st), reps)
+        for t in sorted(times, key=times.get)[:2]:
+            for a in ars:
+                a.tile, a.split = t, -1
+            times[t] = min(times[t], timed(lambda: lib.sr_igemm_group(arr, n, st), 2 * reps))
+        for a, (t, sp) in zip(ars, own):
+            a.tile, a.split = t, sp
+        best = min(times, key=times.get) if times else 0
+        _TUNED[key] = (best, -1) if (times and times[best] < 0.97 * t_seq) else (0, -1)
+        if _TUNE_CACHE:
+            import json as _json
+            with open(_TUNE_CACHE, "w") as _f:
+                _json.dump({_json.dumps([int(x) for x in k]): list(v) for k, v in _TUNED.items()}, _f)
+        if os.environ.get("SR_AUTOTUNE_LOG"):
+            print("[tune group] " + " | ".join(f"B{a.B} {a.H}x{a.W} C{a.C1}+{a.C2} N{a.N} k{a.KH}" for a in ars)
+                  + f" -> seq {t_seq * 1e3:.1f} us, grouped " + " ".join(f"{t}:{v * 1e3:.1f}" for t, v in sorted(times.items()))
+                  + f" -> {_TUNED[key][0]}", flush=True)
+    tile = _TUNED[key][0]
+    if tile == 0:
+        return False
+    for a in ars:
+        a.tile, a.split, a.group = tile, -1, 0
+    ars[0].group = n
+    return True
 
 
 def groupnorm_args(x, gamma, beta, y, B, HW, C1, partials, x2=None, C2=0, groups=32, eps=1e-5, silu=False):

@@ -152,6 +152,17 @@ class PlanBuilder:
         self.flops += f
         self.op_flops[-1] = f
 
+    def igemm_group(self, calls):
+        """calls: [(positional args, kwargs)] of igemm ops that do NOT depend on each other.  They are emitted back to back (so
+        every per-op tool still sees plain igemm ops); when ops.tune_group finds one tile under which a single grouped launch beats
+        the launches one after another, the first op carries ``group = n`` and sr_plan_run hands them to sr_igemm_group."""
+        first = len(self.ops)
+        for args, kw in calls:
+            self.igemm(*args, **kw)
+        members = [op.u.igemm for op in self.ops[first:]]
+        if self._lane == 0 and len(members) == len(calls):
+            O.tune_group(members)
+
     def groupnorm(self, x, gamma, beta, y, B, HW, C1, x2=None, C2=0, eps=1e-5, silu=False):
         need = L.lib().sr_groupnorm_scratch_floats(B, HW)
         if self._gn_scratch is None or self._gn_scratch.numel() < need:

@@ -132,19 +132,28 @@ class BlockLowering:
             er, er_ld = pb.buf(B, Cout, dtype=torch.float32), 0
             pb.igemm(emb_s, W[p + ".emb_layers.1"], er, B, 1, 1, 4 * mc, Cout, bias=W[p + ".emb_layers.1.b"], out_f32=1)
         has_skip = (p + ".skip_connection") in W
+        skip_call = None
         if has_skip:
-            # the 1x1 skip convolution only needs the block input: side lane, beside the GroupNorm / conv path
+            # the 1x1 skip convolution only needs the block input: it rides in the launch of the first 3x3 convolution when the
+            # tuner finds that faster (PlanBuilder.igemm_group) -- or on the side lane (SR_TWO_LANES=1), beside the GroupNorm / conv path
             skip = pb.buf(B, HW, Cout)
-            pb.fork()
-            with pb.side():
-                pb.igemm(x1, W[p + ".skip_connection"], skip, B, hh, ww, C1, Cout, a2=x2, C2=C2, bias=W[p + ".skip_connection.b"])
+            skip_call = ((x1, W[p + ".skip_connection"], skip, B, hh, ww, C1, Cout), dict(a2=x2, C2=C2, bias=W[p + ".skip_connection.b"]))
+            if pb.two_lanes:
+                pb.fork()
+                with pb.side():
+                    pb.igemm(*skip_call[0], **skip_call[1])
+                skip_call = None
         else:
             assert x2 is None and C1 == Cout
             skip = x1
         n1 = pb.buf(B, HW, cin)
         pb.groupnorm(x1, W[p + ".in_layers.0.g"], W[p + ".in_layers.0.beta"], n1, B, HW, C1, x2=x2, C2=C2, eps=1e-5, silu=True)
         hmid = pb.buf(B, HW, Cout)
-        pb.igemm(n1, W[p + ".in_layers.2"], hmid, B, hh, ww, cin, Cout, KH=3, bias=W[p + ".in_layers.2.b"], rowvec=er, rowvec_ld=er_ld)
+        conv1 = ((n1, W[p + ".in_layers.2"], hmid, B, hh, ww, cin, Cout), dict(KH=3, bias=W[p + ".in_layers.2.b"], rowvec=er, rowvec_ld=er_ld))
+        if skip_call is not None:
+            pb.igemm_group([conv1, skip_call])
+        else:
+            pb.igemm(*conv1[0], **conv1[1])
         n2 = pb.buf(B, HW, Cout)
         pb.groupnorm(hmid, W[p + ".out_layers.0.g"], W[p + ".out_layers.0.beta"], n2, B, HW, Cout, eps=1e-5, silu=True)
         if has_skip:
@@ -199,7 +208,8 @@ class BlockLowering:
             k = pb.buf(1, Tk, Cc)
             vt = pb.buf(1, Cc, ldt, zero=True)
             # K/V of the injected frame(s) only (B-fold fewer projection FLOPs); the frame is picked on the device
-            src = pb.buf(nr, HW, Cc)
+            # (rows padded to a whole 128-row tile: as the swapped V^T problem's "weights" the tokens are read tile-wise)
+            src = pb.buf(_cdiv(nr * HW, 128) * 128, Cc, zero=True)[:nr * HW].view(nr, HW, Cc)
             src_st = pb.buf(nr, HW, 2, dtype=torch.float32) if st1 is not None else None
             if self.external:
                 self.schedule.append(("run", pb.take()))
@@ -208,7 +218,12 @@ class BlockLowering:
                 pb.igemm(ln, wq, q, B * HW, 1, 1, Cc, Cc, **kq)
                 self.schedule.append(("run", pb.take()))
                 self.schedule.append(("wait",))
-            # the injected frame's K / V^T are one-frame GEMMs (latency bound): side lane, beside the B-frame Q projection
+            # the injected frame's K / V^T are one-frame GEMMs (latency bound) and independent of the B-frame Q projection: the
+            # three go out as ONE grouped launch when the tuner finds a tile under which that wins (PlanBuilder.igemm_group).
+            # V^T = Wv . src^T is written as the row-major GEMM with the operands' roles swapped -- the packed weight rows
+            # [C, K] are the "pixels", the gathered tokens [Tk, K] the "weights", out[c][t] with row stride Tk -- so that all
+            # three are row-major problems of one kernel (needs ldt == Tk and no folded LayerNorm; else the transposed-output form)
+            swap_v = ldt == Tk and st1 is None and not pb.two_lanes and (p + ".attn1.to_v.b") not in W
             pb.fork()
             with pb.side():
                 if not self.external:
@@ -217,9 +232,16 @@ class BlockLowering:
                         pb.gather_rows(st1, sel, src_st, nr, HW * 2 * 4, B, self.sel_err)
                 wk, kk = lin("attn1.to_k", src_st)
                 wv, kv = lin("attn1.to_v", src_st)
-                pb.igemm(src, wk, k, Tk, 1, 1, Cc, Cc, **kk)
-                pb.igemm(src, wv, vt, 1, Tk, 1, Cc, Cc, transpose_out=1, ldt=ldt, **kv)
-            if not self.external:
+                calls = [((src, wk, k, Tk, 1, 1, Cc, Cc), kk)]
+                if swap_v:
+                    calls.append(((wv, src, vt, Cc, 1, 1, Cc, Tk), {}))
+                else:
+                    calls.append(((src, wv, vt, 1, Tk, 1, Cc, Cc), dict(transpose_out=1, ldt=ldt, **kv)))
+                if not self.external and not pb.two_lanes:
+                    wq, kq = lin("attn1.to_q", st1)
+                    calls.insert(0, ((ln, wq, q, B * HW, 1, 1, Cc, Cc), kq))
+                pb.igemm_group(calls)
+            if not self.external and pb.two_lanes:
                 wq, kq = lin("attn1.to_q", st1)
                 pb.igemm(ln, wq, q, B * HW, 1, 1, Cc, Cc, **kq)
             pb.join()

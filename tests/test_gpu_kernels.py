@@ -211,6 +211,105 @@ def test_igemm_deep_ring_tiles(ops, dtype, case):
         assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 4, 40, 3, 0), (2, 8, 36, 1, 1), (3, 3, 36, 3, 3), (14, 5, 10, 3, 0), (15, 3, 12, 1, 1), (15, 3, 9, 3, 0)])
+def test_igemm_split_fixup_inside_the_gemm(ops, dtype, case, monkeypatch):
+    """split-K finished by the LAST workgroup of a tile to arrive (sr_igemm_args.split_counters): equal to the two-launch form
+    (partials + splitk_reduce_kernel) up to the rounding of the fp16 residual add, bit-equal between launches whichever workgroup
+    arrives last (200 launches, all z-slices of a tile racing), counters back at zero, and against the fp32 convolution"""
+    tile, split, ksteps, KH, act = case
+    dev = "cuda"
+    ke = ops.kelems(dtype)
+    B, H, W, C1, N = 2, 9, 11, ksteps * ke, 328
+    x = rnd(1, B, C1, H, W)
+    w = rnd(2, N, C1, KH, KH) * (C1 * KH * KH) ** -0.5
+    bias, rowvec, resid = rnd(3, N) * 0.1, rnd(4, B, N), rnd(5, B, N, H, W)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), bias, padding=KH // 2) + rowvec[:, :, None, None]
+    ref = {0: lambda v: v, 1: F.silu, 3: F.gelu}[act](ref) + resid.to(dtype).float()
+    xa = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    wp, bp = ops.pack_conv_weight(w, dtype).to(dev), ops.pack_bias(bias).to(dev)
+    M = B * H * W
+    rs = resid.permute(0, 2, 3, 1).reshape(M, N).contiguous().to(dtype).to(dev)
+    kw = dict(KH=KH, bias=bp, rowvec=rowvec.to(dev), residual=rs, act=act, tile=tile, split=split)
+    cnt = ops.split_counters(xa.device)
+    assert int(cnt.abs().sum()) == 0
+    two = torch.zeros(M, N, dtype=dtype, device=dev)
+    ops.igemm(xa, wp, two, B, H, W, C1, N, **kw)                # default: partials + splitk_reduce_kernel
+    torch.cuda.synchronize()
+    monkeypatch.setenv("SR_SPLIT_FIXUP", "1")
+    fused = torch.zeros(M, N, dtype=dtype, device=dev)
+    ops.igemm(xa, wp, fused, B, H, W, C1, N, **kw)
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0, "a tile counter was left non-zero"
+    close(fused.float().cpu().reshape(B, H, W, N).permute(0, 3, 1, 2), ref, dtype, scale=ref.abs().max().item())
+    if dtype == torch.float32:
+        assert torch.equal(fused, two)                         # same z order, same epilogue arithmetic, no intermediate rounding
+    else:                                                      # fp16(fp16(v) + r) against fp16(v + r): half an ulp of v, one of the result
+        d = (fused.float() - two.float()).abs()
+        assert bool((d <= 2.0 ** -10 * (two.float().abs() + rs.float().abs()) + 1e-6).all())
+    for _ in range(200):
+        again = torch.empty_like(fused)
+        ops.igemm(xa, wp, again, B, H, W, C1, N, **kw)
+        assert torch.equal(again, fused)
+    assert int(cnt.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [2, 3, 4, 13, 14, 15, 9, 10])
+def test_igemm_group_one_launch_for_independent_problems(ops, dtype, tile):
+    """sr_igemm_group: the Q projection of B frames, the K projection of one injected frame, its V^T projection written as the
+    operand-swapped row-major problem, and a 3x3 convolution with a concat source run as ONE launch -- bit-equal to the four
+    launches one after another under the same tile, and right against fp32 torch; a group whose members cannot share a kernel
+    (mixed tiles) falls back to single launches with the same results"""
+    import ctypes as C
+    from stable_renderer_amd import _lib as L
+    if tile in (9, 10) and dtype != torch.float16:
+        pytest.skip("fp16 tile")
+    dev = "cuda"
+    ke = ops.kelems(dtype)
+    Cc, HW, B = 320, 192, 3                                   # (N = 320: legal for the 160- / 320-wide tiles too)
+    Tk = 320 if tile in (9, 10) else HW
+    xq, xs = rnd(1, B * HW, Cc), rnd(2, 384, Cc)              # tokens of B frames; the injected frame's tokens (rows padded to a tile)
+    xs[Tk:] = 0
+    wq, wk, wv = (rnd(3 + i, Cc, Cc) * Cc ** -0.5 for i in range(3))
+    xc1, xc2, wc = rnd(7, 2, 64, 6, 5), rnd(8, 2, 128, 6, 5), rnd(9, Cc, 192, 3, 3) * (192 * 9) ** -0.5
+    bias = rnd(10, Cc) * 0.1
+    dq, ds = xq.to(dtype).to(dev), xs.to(dtype).to(dev)
+    pq, pk, pv = (ops.pack_conv_weight(w, dtype).to(dev) for w in (wq, wk, wv))
+    pc, pbias = ops.pack_conv_weight(wc, dtype).to(dev), ops.pack_bias(bias).to(dev)
+    a1 = xc1.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    a2 = xc2.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+
+    def problems():
+        outs = [torch.zeros(B * HW, Cc, dtype=dtype, device=dev), torch.zeros(Tk, Cc, dtype=dtype, device=dev),
+                torch.zeros(Cc, Tk, dtype=dtype, device=dev), torch.zeros(2 * 30, Cc, dtype=dtype, device=dev)]
+        ars = [ops.igemm_args(dq, pq, outs[0], B * HW, 1, 1, Cc, Cc, tile=tile, split=-1),
+               ops.igemm_args(ds, pk, outs[1], Tk, 1, 1, Cc, Cc, tile=tile, split=-1),
+               ops.igemm_args(pv, ds, outs[2], Cc, 1, 1, Cc, Tk, tile=tile, split=-1),           # V^T[c][t] = Wv[c,:] . tokens[t,:]
+               ops.igemm_args(a1, pc, outs[3], 2, 6, 5, 64, Cc, KH=3, a2=a2, C2=128, bias=pbias, act=1, tile=tile, split=-1)]
+        return ars, outs
+    ars, single = problems()
+    for ar in ars:
+        L.check(L.lib().sr_igemm(C.byref(ar), ops.stream_ptr()))
+    ars_g, grouped = problems()
+    ops.igemm_group(ars_g)
+    torch.cuda.synchronize()
+    for s_, g_ in zip(single, grouped):
+        assert torch.equal(s_, g_)
+    h = lambda t: t.to(dtype).float()
+    close(grouped[0], h(xq) @ h(wq).T, dtype, scale=3.0)
+    close(grouped[1], h(xs[:Tk]) @ h(wk).T, dtype, scale=3.0)
+    close(grouped[2], h(wv) @ h(xs[:Tk]).T, dtype, scale=3.0)
+    refc = F.silu(F.conv2d(torch.cat([h(xc1), h(xc2)], 1), h(wc), bias, padding=1))
+    close(grouped[3].float().cpu().reshape(2, 6, 5, Cc).permute(0, 3, 1, 2), refc, dtype, scale=refc.abs().max().item())
+    ars_m, mixed = problems()                                  # members that cannot share a kernel: launched one by one
+    ars_m[1].tile = 4 if tile != 4 else 3
+    ops.igemm_group(ars_m[:3])
+    torch.cuda.synchronize()
+    assert torch.equal(mixed[0], single[0]) and torch.equal(mixed[2], single[2])
+    close(mixed[1], h(xs[:Tk]) @ h(wk).T, dtype, scale=3.0)
+
+
 def test_cold_state_tuner_and_cache_touch(ops, monkeypatch):
     """the tile tuner's measurement state (cache flush + sr_cache_touch of the activations / residual): sr_cache_touch accepts any
     16-byte-aligned range and rejects null / unaligned pointers; a freshly tuned shape (not in any table) ends on a legal

@@ -12,7 +12,8 @@ dt = torch.float16
 shapes = [(512, 1, 1, 1280, 1280, 1), (2048, 1, 1, 640, 640, 1), (8192, 1, 1, 320, 320, 1), (128, 1, 1, 1280, 1280, 1),
           (2, 8, 8, 1280, 1280, 3), (2, 16, 16, 1280, 1280, 3), (2, 32, 32, 640, 640, 3), (2, 64, 64, 320, 320, 3),
           (2048, 1, 1, 2560, 640, 1), (512, 1, 1, 5120, 1280, 1), (4096, 1, 1, 1280, 1280, 1), (16, 16, 16, 1280, 1280, 3), (16, 8, 8, 1280, 1280, 3)]
-cands = [(0, 0), (2, -1), (2, 0), (3, -1), (3, 0), (4, -1), (13, -1), (14, -1), (14, 2), (14, 3), (14, 4), (14, 5), (15, -1), (15, 2), (15, 4)]
+cands = [(0, 0), (2, -1), (2, 0), (2, 2), (2, 4), (2, 8), (3, -1), (3, 0), (3, 4), (3, 8), (4, -1), (13, -1), (14, -1), (14, 2), (14, 3), (14, 4), (14, 5), (14, 8), (14, 12), (14, 16),
+         (15, -1), (15, 2), (15, 4), (15, 8), (15, 12)]
 flush = torch.empty(600 << 20, dtype=torch.uint8, device="cuda") if cold else None
 lib = L.lib()
 for (B, H, W, Cc, N, KH) in shapes:
