@@ -123,8 +123,9 @@ int sr_igemm_group(const sr_igemm_args* const* args, int32_t n, void* stream);
 
 /* GroupNorm(32 groups) [+SiLU] over NHWC, optional channel concat of two sources (th.cat([h, hsp]) in
  * UNetModel.forward, openaimodel.py:921).  Replaces GroupNorm32 + SiLU in ResBlock.in_layers/out_layers,
- * SpatialTransformer.norm (eps 1e-6), VAE Normalize.  `partials` scratch: B*chunks*64 floats (see
- * sr_groupnorm_scratch_floats). */
+ * SpatialTransformer.norm (eps 1e-6), VAE Normalize.  `partials` scratch: sr_groupnorm_scratch_floats(B, HW) floats -- the largest
+ * need of any batch up to B (small batches use more, smaller pixel chunks), so a buffer sized for a host's largest batch serves
+ * every smaller one. */
 typedef struct {
   const void* x; const void* x2;      /* [B, HW, C1], [B, HW, C2] or NULL */
   const float* gamma; const float* beta;  /* [C1+C2] fp32 */

@@ -374,6 +374,136 @@ bool try_gn_fused(const sr_groupnorm_args* a, hipStream_t st) {
   return true;
 }
 
+// The same slab-in-registers GroupNorm with the reductions done by wave shuffles: ONE workgroup barrier per moment instead of four
+// (write per-thread sums -> strip sums -> column sums -> group statistic), no serial LDS loops, the affine parameters requested
+// with the slab.  Written for small batches (a one-view rank of the 8-GPU shard evaluates B = 2): there a launch is 16-64
+// workgroups, nothing overlaps a workgroup's dependent chain, and the chain -- not bandwidth -- is the kernel's time
+// (B 2, 8x8 x 1280: 12.6 us with the LDS form for 330 KB of traffic).  A thread folds its 8-channel sums to the (at most GB)
+// groups they belong to, every group's value is reduced across the wave by xor-shuffles, lane 0 publishes one value per group and
+// wave, and after the barrier every thread adds the waves in wave order: fixed order, bit-reproducible.  Mean first, then the
+// centred second moment (no E[x^2] - mean^2 cancellation), as above.
+template <typename T, int NV, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void gn_wave_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y, int HW, int C1, int C2,
+                                                        int groups, int GB, float eps, int silu) {
+  constexpr int EPC = sr_traits<T>::EPC, NW = BLOCK / 64, GMAX = 8;
+  using VEC = typename std::conditional<sizeof(T) == 2, h16x8, f32x4>::type;
+  __shared__ float wsum[2][NW][GMAX];
+  __shared__ float aff[2][512];                              // gamma / beta of the bundle's channels (span <= 512)
+  const int C = C1 + C2, cpg = C / groups, span = GB * cpg, vpp = span / EPC, pp = BLOCK / vpp;
+  const int nb = groups / GB, wg = sr_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wg / nb, bundle = wg - b * nb, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cc = tid % vpp, ps = tid / vpp;
+  const bool active = ps < pp;
+  const int cl = cc * EPC, c0 = bundle * span + cl;
+  const T* src = c0 < C1 ? x1 + (int64_t)b * HW * C1 + c0 : x2 + (int64_t)b * HW * C2 + (c0 - C1);
+  const int cs = c0 < C1 ? C1 : C2;
+  VEC raw[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = ps + i * pp;
+    if (active && p < HW) raw[i] = *(const VEC*)(src + (int64_t)p * cs);
+  }
+  for (int c = tid; c < span; c += BLOCK) { aff[0][c] = gamma[bundle * span + c]; aff[1][c] = beta[bundle * span + c]; }   // (visible after the barriers below)
+  // the thread's 8 (4) channels lie in at most two groups (cpg >= EPC / 2): g0 and, from element eb on, g0 + 1
+  const int g0 = cl / cpg, eb = (g0 + 1) * cpg - cl;
+  const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+  float mean0 = 0.f, mean1 = 0.f, rstd0 = 0.f, rstd1 = 0.f;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int p = ps + i * pp;
+      if (active && p < HW) {
+        float v[EPC];
+        VEC r = raw[i];
+        asm volatile("" : "+v"(r));                        // keep the slab packed in registers: no hoisted fp32 copies
+        load_chunk<T>((const T*)&r, v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          if (round == 0) acc[e] += v[e];
+          else { const float d = v[e] - (e < eb ? mean0 : mean1); acc[e] += d * d; }
+        }
+      }
+    }
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { if (e < eb) t0 += acc[e]; else t1 += acc[e]; }
+    for (int g = 0; g < GB; ++g) {                           // (GB is uniform)
+      float t = (g == g0 ? t0 : 0.f) + (g == g0 + 1 ? t1 : 0.f);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+      if (lane == 0) wsum[round][wv][g] = t;
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+    const int g1 = g0 + 1 < GB ? g0 + 1 : g0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { a0 += wsum[round][w][g0]; a1 += wsum[round][w][g1]; }
+    if (round == 0) { mean0 = a0 * inv_cnt; mean1 = a1 * inv_cnt; }
+    else { rstd0 = rsqrtf(a0 * inv_cnt + eps); rstd1 = rsqrtf(a1 * inv_cnt + eps); }
+  }
+  if (!active) return;
+  float sc[EPC], sh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    sc[e] = (e < eb ? rstd0 : rstd1) * aff[0][cl + e];
+    sh[e] = aff[1][cl + e] - (e < eb ? mean0 : mean1) * sc[e];
+  }
+  T* dst = y + (int64_t)b * HW * C + c0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = ps + i * pp;
+    if (p < HW) {
+      float v[EPC];
+      VEC r = raw[i];
+      asm volatile("" : "+v"(r));
+      load_chunk<T>((const T*)&r, v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float t = v[e] * sc[e] + sh[e];
+        v[e] = silu ? sr_silu_f(t) : t;
+      }
+      store_chunk<T>(dst + (int64_t)p * C, v);
+    }
+  }
+}
+
+template <typename T, int NV, int BLOCK>
+void launch_gn_wave(const sr_groupnorm_args* a, int GB, hipStream_t st) {
+  hipLaunchKernelGGL((gn_wave_kernel<T, NV, BLOCK>), dim3((a->groups / GB) * a->B), dim3(BLOCK), 0, st, (const T*)a->x, (const T*)a->x2,
+                     a->gamma, a->beta, (T*)a->y, a->HW, a->C1, a->C2, a->groups, GB, a->eps, a->silu);
+}
+
+// -> true when the shuffle-reduced kernel took the job: launches of few workgroups (small batches), where the dependent chain of
+// one workgroup is the whole kernel; maps up to 32x32
+template <typename T>
+bool try_gn_wave(const sr_groupnorm_args* a, hipStream_t st) {
+  constexpr int EPC = sr_traits<T>::EPC;
+  const int C = a->C1 + a->C2, cpg = C / a->groups;
+  int GB = 0;
+  for (int g = 1; g <= 8; ++g)
+    if ((g * cpg) % EPC == 0 && a->groups % g == 0) { GB = g; break; }
+  if (!GB) return false;
+  const int vpp = GB * cpg / EPC;
+  if (vpp > 64 || GB * cpg > 512 || 2 * cpg < EPC) return false;      // (a thread's chunk may straddle two groups, not more)
+  static const int max_wg = getenv("SR_GN_WAVE_MAX_WG") ? atoi(getenv("SR_GN_WAVE_MAX_WG")) : 256;   // tuning / A-B aid (0 = off)
+  if ((a->groups / GB) * a->B > max_wg) return false;
+  auto need = [&](int block) { return sr_cdiv(a->HW, block / vpp); };
+  if (need(64) <= 8) launch_gn_wave<T, 8, 64>(a, GB, st);
+  else if (need(256) <= 4) launch_gn_wave<T, 4, 256>(a, GB, st);
+  else if (need(256) <= 8) launch_gn_wave<T, 8, 256>(a, GB, st);
+  else if (need(1024) <= 8) launch_gn_wave<T, 8, 1024>(a, GB, st);
+  else if (need(1024) <= 16) launch_gn_wave<T, 16, 1024>(a, GB, st);
+  // (64x64 x 320 maps need 21 chunks per thread of a 1024-thread block: 20-24 spilled registers and 16 workgroups per batch pair --
+  //  38 us against 20.5 us for the two-pass kernels at B = 2; left to them)
+  else return false;
+  return true;
+}
+
 // one wave per row
 // One wave per ROWS consecutive rows (MAXC 16-byte chunks per lane and row): with one 640-byte row per wave the kernel is a chain
 // load -> two shuffle trees -> store with ~20 KB in flight per CU (3.2 TB/s at rows 65536, C 320); ROWS independent rows per
@@ -544,7 +674,14 @@ extern "C" int sr_row_stats(const void* x, float* stats, int32_t rows, int32_t C
 }
 
 extern "C" int64_t sr_groupnorm_scratch_floats(int32_t B, int32_t HW) {
-  return (int64_t)B * sr_cdiv(HW, gn_ppc(HW, B)) * 64 * 2;
+  // small batches cut an entry into more chunks (gn_ppc), so the need is not monotonic in B: return the largest need of any batch
+  // up to B -- a host that sized `partials` once for its largest batch stays safe for every smaller one
+  int64_t need = 0;
+  for (int b = 1; b <= B; ++b) {
+    const int64_t n = (int64_t)b * sr_cdiv(HW, gn_ppc(HW, b)) * 64 * 2;
+    need = n > need ? n : need;
+  }
+  return need;
 }
 
 extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
@@ -560,6 +697,10 @@ extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
   if (lds > 64 * 1024) SR_FAIL(SR_ERR_INVALID, "sr_groupnorm: C too large");
   hipStream_t st = sr_stream(stream);
   static const bool no_fused = getenv("SR_GN_TWO_PASS") != nullptr;      // tuning / A-B aid
+  if (!no_fused && (a->dtype == SR_F16 ? try_gn_wave<_Float16>(a, st) : a->dtype == SR_F32 ? try_gn_wave<float>(a, st) : false)) {
+    SR_CHECK_LAUNCH("sr_groupnorm");
+    return SR_OK;
+  }
   if (!no_fused && (a->dtype == SR_F16 ? try_gn_fused<_Float16>(a, st) : a->dtype == SR_F32 ? try_gn_fused<float>(a, st) : false)) {
     SR_CHECK_LAUNCH("sr_groupnorm");
     return SR_OK;
