@@ -322,6 +322,11 @@ int sr_adain(const float* content, int64_t c_ps, int64_t c_cs, int64_t c_ns, int
  * stats: optional scratch of 2048 floats -- with it the style statistics are reduced by 256 workgroups instead of 4. */
 int sr_noise_pool(const void* noise_f16, const void* alpha_f16, const float* bg, float* pooled, float* out,
                   int32_t H, int32_t W, float* stats, void* stream);
+/* The same with `strip` consecutive pixels per mean instead of 64: NoiseSequenceLoader pools with reshape_magnitude m = H // 64
+ * (SD15) or H // 128 (SDXL), i.e. view(-1, m, m, 4).mean((1, 2)) = means of m*m consecutive pixels, viewed (H/m, W/m)
+ * (comfyUI/stable_rendering/_nodes/loaders.py:131-146).  pooled: (H*W/strip, 4) fp32, out: (1, 4, H*W/strip) fp32. */
+int sr_noise_pool_strips(const void* noise_f16, const void* alpha_f16, const float* bg, float* pooled, float* out,
+                         int32_t H, int32_t W, int32_t strip, float* stats, void* stream);
 
 /* CorrespondMap._update (engine/static/corrmap.py:672-736) for ONE frame, deterministic last-writer-wins.
  * frame (H*W, Cf) fp32 (Cf = 3: alpha 1 appended, corrmap.py:684), ids (H*W,4) int32, mask (H*W) fp32 or NULL

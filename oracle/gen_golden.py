@@ -7,6 +7,7 @@ Outputs small ``.npz`` fixtures under ``tests/golden/``.  The reference sources 
 arithmetic (torch / einops / scipy) is real, so these vectors are authoritative reference outputs.
 Nothing here runs on the GPU box.  Every fixture stores inputs (or the seeds that make them) + outputs.
 """
+import ast
 import contextlib
 import io
 import json
@@ -644,6 +645,37 @@ def sec_dump():
     save("corrmap_dump_io", values_in=m._values, writtens_in=m._writtens, values_back=m2._values, writtens_back=m2._writtens)
 
 
+def ref_noise_sequence_loader():
+    """-> the reference's NoiseSequenceLoader.__call__ (_nodes/loaders.py:79-152) as a plain function(self, directory, frame_start,
+    num_frames, sd_version): compiled from the reference's own source text at generation time (the _nodes package itself drags in
+    the GL engine), node-type annotations dropped, with the reference's adaptive_instance_normalization"""
+    lsrc = open(os.path.join(R.REF, "source/comfyUI/stable_rendering/_nodes/loaders.py")).read()
+    ltree = ast.parse(lsrc)
+    lcls = next(n for n in ltree.body if isinstance(n, ast.ClassDef) and n.name == "NoiseSequenceLoader")
+    call = next(n for n in lcls.body if isinstance(n, ast.FunctionDef) and n.name == "__call__")
+    call.args.defaults = []
+    for a in call.args.args:                                                   # drop the node-type annotations
+        a.annotation = None
+    call.returns = None
+    ast.fix_missing_locations(call)
+    mu = R.import_math_utils() if hasattr(R, "import_math_utils") else __import__("common_utils.math_utils", fromlist=["x"])
+    import re as _re
+
+    def extract_index(name, default):
+        m = _re.findall(r"\d+", os.path.splitext(name)[0])
+        return int(m[-1]) if m else default
+
+    class _L:
+        @staticmethod
+        def debug(*a, **k):
+            pass
+    lns = dict(os=os, np=np, torch=torch, extract_index=extract_index, ComfyUILogger=_L,
+               adaptive_instance_normalization=mu.adaptive_instance_normalization,
+               LATENT=lambda **kw: dict(kw))
+    exec(compile(ast.Module(body=[call], type_ignores=[]), "loaders.py[NoiseSequenceLoader.__call__]", "exec"), lns)
+    return lns["__call__"]
+
+
 def sec_gbufdump():
     """G-buffer dump layout (DiffusionManager._outputMap/_outputNumpyData/_outputDepthMap, diffusionManager.py:160-259).
     The manager module cannot be imported here (its package pulls the GL managers), so the three methods are taken from the
@@ -703,30 +735,7 @@ def sec_gbufdump():
     shutil.rmtree(tmp)
     # NoiseSequenceLoader.__call__ (_nodes/loaders.py:79-152) on two seeded 512^2 fp16 noise dumps (inputs are re-made from
     # the seeds in the test; only the loader's output is stored)
-    lsrc = open(os.path.join(R.REF, "source/comfyUI/stable_rendering/_nodes/loaders.py")).read()
-    ltree = ast.parse(lsrc)
-    lcls = next(n for n in ltree.body if isinstance(n, ast.ClassDef) and n.name == "NoiseSequenceLoader")
-    call = next(n for n in lcls.body if isinstance(n, ast.FunctionDef) and n.name == "__call__")
-    call.args.defaults = []
-    for a in call.args.args:                                                   # drop the node-type annotations
-        a.annotation = None
-    call.returns = None
-    ast.fix_missing_locations(call)
-    mu = R.import_math_utils() if hasattr(R, "import_math_utils") else __import__("common_utils.math_utils", fromlist=["x"])
-    import re as _re
-
-    def extract_index(name, default):
-        m = _re.findall(r"\d+", os.path.splitext(name)[0])
-        return int(m[-1]) if m else default
-
-    class _L:
-        @staticmethod
-        def debug(*a, **k):
-            pass
-    lns = dict(os=os, np=np, torch=torch, extract_index=extract_index, ComfyUILogger=_L,
-               adaptive_instance_normalization=mu.adaptive_instance_normalization,
-               LATENT=lambda **kw: dict(kw))
-    exec(compile(ast.Module(body=[call], type_ignores=[]), "loaders.py[NoiseSequenceLoader.__call__]", "exec"), lns)
+    lns = {"__call__": ref_noise_sequence_loader()}
     tmp2 = tempfile.mkdtemp()
     for i, seed in enumerate((21, 22)):
         np.save(os.path.join(tmp2, f"noise_{i}.npy"), np.random.default_rng(seed).standard_normal((512, 512, 4)).astype(np.float16))
@@ -812,6 +821,52 @@ def sec_conds():
     save("cond_compose", **out)
 
 
+def cond_range_case():
+    """entries with ConditioningSetTimestepRange windows (start_percent / end_percent, comfyUI/nodes.py:270-285): the second
+    positive prompt acts in the middle of the schedule only, the negative prompt in its first half only"""
+    def c(seed):
+        return rnd(seed, 1, 5, 6)
+    pos = [[c(31), {}], [c(32), {"start_percent": 0.3, "end_percent": 0.7, "strength": 0.8}]]
+    neg = [[c(33), {"start_percent": 0.0, "end_percent": 0.5}]]
+    return pos, neg, 5.0, [14.0, 6.0, 2.5, 1.2, 0.6, 0.2]
+
+
+def sec_cond_ranges():
+    """get_area_and_mult's sigma windows (samplers.py:60-67) through calculate_start_end_timesteps (:578-602) with the reference's
+    ModelSamplingDiscrete.percent_to_sigma, sampling_function evaluated at sigmas inside and outside the windows (toy model)"""
+    import comfy.model_sampling as cms
+    import comfy.samplers as cs
+    import comfy.sample as csm
+
+    class Toy:
+        model_sampling = cms.ModelSamplingDiscrete(None)
+
+        def memory_required(self, shape):
+            return 0
+
+        def apply_model(self, x, t, c_crossattn=None, transformer_options=None, **kw):
+            b = x.shape[0]
+            return (x * 0.5 + c_crossattn.mean(dim=(1, 2)).view(-1, 1, 1, 1) + 0.01 * t.view(-1, 1, 1, 1)
+                    + 0.001 * torch.arange(b, dtype=torch.float32).view(-1, 1, 1, 1))
+    pos, neg, scale, sigmas = cond_range_case()
+    x = rnd(40, 2, 4, 16, 24)
+    p, n = csm.convert_cond(pos), csm.convert_cond(neg)
+    cs.resolve_areas_and_cond_masks(p, 16, 24, "cpu")
+    cs.resolve_areas_and_cond_masks(n, 16, 24, "cpu")
+    toy = Toy()
+    cs.calculate_start_end_timesteps(toy, n)
+    cs.calculate_start_end_timesteps(toy, p)
+    out = {"x": x, "sigmas": np.array(sigmas, np.float32), "scale": np.float32(scale),
+           "windows": np.array([[e.get("timestep_start", -1.0), e.get("timestep_end", -1.0)] for e in p + n], np.float64)}
+    for i, sg in enumerate(sigmas):
+        with quiet():
+            out[f"cfg_{i}"] = cs.sampling_function(toy, x, torch.tensor([sg, sg]), n, p, scale, {})
+    for kind, lst in (("pos", pos), ("neg", neg)):
+        for i, (t, _) in enumerate(lst):
+            out[f"{kind}{i}_c"] = t
+    save("cond_ranges", **out)
+
+
 def sec_workflow():
     """(1) the reference's own Workflow.Load + build_prompt (engine/static/workflow.py) on every shipped example graph: the
     prompt dict, the output-node ids, or the exception type the reference raises for that file; (2) comfy's LoRA key map
@@ -887,7 +942,7 @@ def sec_workflow():
 
 SECTIONS = dict(math=sec_math, idmap=sec_idmap, overlap=sec_overlap, corrmap=sec_corrmap, noisepool=sec_noisepool,
                 sched=sec_sched, unet=sec_unet, vae=sec_vae, e2e=sec_e2e, dump=sec_dump, controlnet=sec_controlnet, legacy=sec_legacy,
-                gbufdump=sec_gbufdump, workflow=sec_workflow, sdxl=sec_sdxl, conds=sec_conds, vaeenc=sec_vaeenc)
+                gbufdump=sec_gbufdump, workflow=sec_workflow, sdxl=sec_sdxl, conds=sec_conds, cond_ranges=sec_cond_ranges, vaeenc=sec_vaeenc)
 
 if __name__ == "__main__":
     todo = _ARGV or list(SECTIONS)

@@ -327,7 +327,42 @@ def sec_nrand2():
             samples=s, e2e_inj=np.array(inj), rng_seed=np.array(4242))
 
 
-SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, config4=sec_config4, bench8=sec_bench8, bench8_20=sec_bench8_20,
+# ---- BASELINE config 1 through the reference's LOADER nodes on the reference's own dumps (VERDICT r3 missing #4) ---------------
+def sec_config1_dumps():
+    """"pre-dumped G-buffers, 256x256, 4 steps, 1 view": every second pixel of one frame of the reference's shipped dumps (ids:
+    resources/example-sphere-and-object-views/sphere/id, noise: resources/example-map-outputs/miku-sphere/noise -- the sphere's own
+    noise dumps are all zeros) written as a 256x256 dump directory, read back by the reference's IDSequenceLoader /
+    NoiseSequenceLoader (reshape_magnitude = 256 // 64 = 4: means of 16 consecutive pixels, viewed 64 x 64 -- _nodes/loaders.py:
+    131-146), sampled by the reference stack (euler / sgm_uniform, cfg 2, 4 steps, the CorrespondSampler call) and decoded"""
+    import tempfile
+    attention_basic()
+    cm = R.import_corrmap()
+    noise_loader = GG.ref_noise_sequence_loader()             # NoiseSequenceLoader.__call__ compiled from the reference's source
+    t0 = time.time()
+    res = "/root/reference/resources"
+    ids = np.load(os.path.join(res, "example-sphere-and-object-views", "sphere", "id", "id_0.npy"))[::2, ::2].copy()
+    nz = np.load(os.path.join(res, "example-map-outputs", "miku-sphere", "noise", "noise_0.npy"))[::2, ::2].copy()
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "id")); os.makedirs(os.path.join(td, "noise"))
+        np.save(os.path.join(td, "id", "id_0.npy"), ids)
+        np.save(os.path.join(td, "noise", "noise_0.npy"), nz)
+        with GG.quiet():
+            # IDSequenceLoader.__call__ is this one call (_nodes/loaders.py:312-326)
+            idmap = cm.IDMap.from_directory(directory=os.path.join(td, "id"), frame_start=0, num_frames=1, use_frame_indices_from_filename=False)
+            lat = noise_loader(None, os.path.join(td, "noise"), 0, 1, "SD15")
+    noise = lat["noise"].float()
+    assert tuple(noise.shape) == (1, 4, 64, 64), noise.shape
+    mp, ns, _ = ref_model(GG.SD15, 0)
+    s, _ = ref_sample(mp, noise, [[ctx(1), {}]], [[ctx(2), {}]], None, 4, 2.0, "euler", "sgm_uniform", 7)
+    img = ref_decode(s)
+    GG.save("full_config1_dumps", id_dump=ids, noise_dump=nz, loader_ids=idmap.tensor.cpu().numpy(), loader_noise=noise, samples=s,
+            img_sub=sub4(img), meta=np.frombuffer(json.dumps(dict(views=1, steps=4, sampler="euler", scheduler="sgm_uniform", cfg=2.0,
+                                                                  rng_seed=7, pos_seed=1, neg_seed=2, unet_seed=0, vae_seed=2,
+                                                                  size=256)).encode(), np.uint8))
+    print("config1_dumps: %.0f s" % (time.time() - t0))
+
+
+SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, config4=sec_config4, bench8=sec_bench8, bench8_20=sec_bench8_20, config1_dumps=sec_config1_dumps,
                 config2=sec_config2, config3=sec_config3)
 
 if __name__ == "__main__":

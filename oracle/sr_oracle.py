@@ -507,7 +507,7 @@ def sample_frames(sd, cfg, noise, pos, neg, ids, steps, cfg_scale, sampler, sche
 
     entries = None
     if cond_entries is not None:                            # (pos entries, neg entries): masks / strengths / areas
-        entries = prepare_cond_entries(cond_entries[0], cond_entries[1], noise.shape[2], noise.shape[3])
+        entries = prepare_cond_entries(cond_entries[0], cond_entries[1], noise.shape[2], noise.shape[3], ms)
 
     def denoise_fn(xx, sigma):
         if entries is not None:
@@ -641,6 +641,39 @@ def area_and_mult(e, x):
     return ix, mult, area
 
 
+def percent_to_sigma(ms, percent):
+    """ModelSamplingDiscrete.percent_to_sigma (comfy/model_sampling.py:138-144)"""
+    if percent <= 0.0:
+        return 999999999.9
+    if percent >= 1.0:
+        return 0.0
+    return float(ms.sigma(torch.tensor((1.0 - percent) * 999.0)))
+
+
+def with_timestep_ranges(entries, ms):
+    """calculate_start_end_timesteps (samplers.py:578-602): start_percent / end_percent -> timestep_start / timestep_end (sigmas)"""
+    out = []
+    for e in entries:
+        if "start_percent" in e or "end_percent" in e:
+            e = dict(e)
+            if "start_percent" in e:
+                e["timestep_start"] = percent_to_sigma(ms, e["start_percent"])
+            if "end_percent" in e:
+                e["timestep_end"] = percent_to_sigma(ms, e["end_percent"])
+        out.append(e)
+    return out
+
+
+def entry_active(e, sigma0):
+    """get_area_and_mult's first test (samplers.py:60-67): an entry outside its sigma window returns None -- it is not run at
+    this step and contributes nothing to out / count"""
+    if "timestep_start" in e and sigma0 > e["timestep_start"]:
+        return False
+    if "timestep_end" in e and sigma0 < e["timestep_end"]:
+        return False
+    return True
+
+
 def calc_cond_uncond_batch(model_fn, cond, uncond, x, sigma):
     """model_fn(input_x (B,4,ah,aw), sigma (B,), ctx (B,T,C)) -> DENOISED prediction (apply_model's return).  Entries whose
     cropped input has the same shape and token count run as ONE batch, in the reference's order: the batchable entries of
@@ -649,8 +682,9 @@ def calc_cond_uncond_batch(model_fn, cond, uncond, x, sigma):
     out_c, cnt_c = torch.zeros_like(x), torch.ones_like(x) * 1e-37
     out_u, cnt_u = torch.zeros_like(x), torch.ones_like(x) * 1e-37
     n = x.shape[0]
-    to_run = [(area_and_mult(e, x), 0, ("pos", i), e) for i, e in enumerate(cond or [])]
-    to_run += [(area_and_mult(e, x), 1, ("neg", i), e) for i, e in enumerate(uncond or [])]
+    s0 = float(sigma.reshape(-1)[0])
+    to_run = [(area_and_mult(e, x), 0, ("pos", i), e) for i, e in enumerate(cond or []) if entry_active(e, s0)]
+    to_run += [(area_and_mult(e, x), 1, ("neg", i), e) for i, e in enumerate(uncond or []) if entry_active(e, s0)]
     batches = []
     while to_run:
         first = to_run[0]
@@ -677,9 +711,12 @@ def sampling_function(model_fn, x, sigma, uncond, cond, cond_scale):
     return u + (c - u) * cond_scale
 
 
-def prepare_cond_entries(pos, neg, h, w):
-    """samplers.sample() :887-912 for mask / area entries: resolve both lists, then give every area an opposite entry"""
+def prepare_cond_entries(pos, neg, h, w, ms=None):
+    """samplers.sample() :887-912 for mask / area entries: resolve both lists, percent ranges -> sigma windows (with a model
+    sampling object), then give every area an opposite entry"""
     pos, neg = resolve_entries(pos, h, w), resolve_entries(neg, h, w)
+    if ms is not None:
+        neg, pos = with_timestep_ranges(neg, ms), with_timestep_ranges(pos, ms)
     for c in list(pos):
         add_opposite_areas(neg, c)
     for c in list(neg):

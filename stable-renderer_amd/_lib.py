@@ -142,6 +142,7 @@ SYMBOLS = {
     "sr_nearest_resize": (C.c_int, [vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     "sr_adain": (C.c_int, [vp, i64, i64, i64, i32, vp, i32, i64, i64, i64, i32, vp, i32, i32, f32, vp, vp]),
     "sr_noise_pool": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "sr_noise_pool_strips": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "sr_corrmap_update": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
     "sr_gbuffer_clear": (C.c_int, [P(GBuffer), vp]),
     "sr_gbuffer_depth_merge": (C.c_int, [P(GBuffer), P(GBuffer), vp]),

@@ -30,19 +30,57 @@ def entries_of(conditioning):
     return out
 
 
-# keys get_area_and_mult / calc_cond_uncond_batch act on that this package does not implement: an entry carrying one of them
-# is refused instead of being run as if the key were absent (the reference skips such an entry outside its sigma range,
-# samplers.py:62-69, and feeds gligen boxes to the transformer blocks, :103-115)
-_UNSUPPORTED_KEYS = ("timestep_start", "timestep_end", "start_percent", "end_percent", "gligen")
+# a key calc_cond_uncond_batch acts on that this package does not implement: an entry carrying it is refused instead of being
+# run as if the key were absent (the reference feeds gligen boxes to the transformer blocks, samplers.py:103-115)
+_UNSUPPORTED_KEYS = ("gligen",)
 
 
 def check_supported(entries):
     for e in entries:
-        bad = [k for k in _UNSUPPORTED_KEYS if e.get(k) is not None and not (k == "start_percent" and float(e[k]) == 0.0)
-               and not (k == "end_percent" and float(e[k]) == 1.0)]
+        bad = [k for k in _UNSUPPORTED_KEYS if e.get(k) is not None]
         if bad:
-            raise NotImplementedError("conditioning entry carries %s (ConditioningSetTimestepRange / GLIGEN): not implemented, "
-                                      "refusing to run it at every step" % ", ".join(bad))
+            raise NotImplementedError("conditioning entry carries %s (GLIGEN): not implemented, refusing to run it without"
+                                      % ", ".join(bad))
+
+
+def percent_to_sigma(ms, percent):
+    """ModelSamplingDiscrete.percent_to_sigma (comfy/model_sampling.py:138-144)"""
+    if percent <= 0.0:
+        return 999999999.9
+    if percent >= 1.0:
+        return 0.0
+    return float(ms.sigma(torch.tensor((1.0 - percent) * 999.0)))
+
+
+def with_timestep_ranges(entries, ms):
+    """calculate_start_end_timesteps (comfy/samplers.py:578-602): ConditioningSetTimestepRange's start_percent / end_percent
+    (comfyUI/nodes.py:270-285) become the sigma window [timestep_end, timestep_start] of the entry"""
+    out = []
+    for e in entries:
+        if "start_percent" in e or "end_percent" in e:
+            e = dict(e)
+            if "start_percent" in e:
+                e["timestep_start"] = percent_to_sigma(ms, float(e["start_percent"]))
+            if "end_percent" in e:
+                e["timestep_end"] = percent_to_sigma(ms, float(e["end_percent"]))
+        out.append(e)
+    return out
+
+
+def entry_active(e, sigma):
+    """get_area_and_mult's first test (comfy/samplers.py:60-67): outside its sigma window an entry is not run at this step and
+    adds nothing to out / count"""
+    if e.get("timestep_start") is not None and sigma > e["timestep_start"]:
+        return False
+    if e.get("timestep_end") is not None and sigma < e["timestep_end"]:
+        return False
+    return True
+
+
+def has_window(e):
+    """the entry can be inactive at some sigma"""
+    return (e.get("timestep_start") is not None or e.get("timestep_end") is not None
+            or float(e.get("start_percent", 0.0)) > 0.0 or float(e.get("end_percent", 1.0)) < 1.0)
 
 
 def is_plain(entries):
@@ -51,7 +89,7 @@ def is_plain(entries):
     if len(entries) != 1:
         return False
     e = entries[0]
-    return e.get("mask") is None and e.get("area") is None and float(e.get("strength", 1.0)) == 1.0
+    return e.get("mask") is None and e.get("area") is None and float(e.get("strength", 1.0)) == 1.0 and not has_window(e)
 
 
 def resolve_entries(entries, h, w):
@@ -108,8 +146,11 @@ def add_opposite_area(conds, c):
     conds.append(o)
 
 
-def prepare(pos, neg, h, w):
+def prepare(pos, neg, h, w, ms=None):
+    """samplers.sample() :887-912: resolve, sigma windows (ms: the model sampling object), opposite-area entries"""
     pos, neg = resolve_entries(pos, h, w), resolve_entries(neg, h, w)
+    if ms is not None:
+        neg, pos = with_timestep_ranges(neg, ms), with_timestep_ranges(pos, ms)
     for c in list(pos):
         add_opposite_area(neg, c)
     for c in list(neg):

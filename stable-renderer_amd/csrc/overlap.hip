@@ -308,21 +308,22 @@ __global__ __launch_bounds__(256) void style_partial_rgba16(const _Float16* __re
   }
 }
 
-// 64-pixel strip means of noise*(1-mask) + bg*mask (renderManager.py:929-932)
+// strip means (`strip` consecutive pixels of the flattened image: 64 in the engine, renderManager.py:929-932; m*m in the loader,
+// _nodes/loaders.py:131-146) of noise*(1-mask) + bg*mask
 __global__ void noise_pool_kernel(const _Float16* __restrict__ noise, const _Float16* __restrict__ alpha, const float* __restrict__ bg,
-                                  float* __restrict__ pooled, int ngroups) {
+                                  float* __restrict__ pooled, int ngroups, int strip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;      // over ngroups*4
   if (i >= ngroups * 4) return;
   const int g = i >> 2, c = i & 3;
   float s = 0.f;
-  for (int k = 0; k < 64; ++k) {
-    const int64_t px = (int64_t)g * 64 + k;
+  for (int k = 0; k < strip; ++k) {
+    const int64_t px = (int64_t)g * strip + k;
     const _Float16 m = (_Float16)(1.0f - (float)alpha[px]);            // mask = 1 - alpha (fp16)
     const _Float16 om = (_Float16)(1.0f - (float)m);
     const _Float16 a = (_Float16)((float)noise[px * 4 + c] * (float)om); // fp16 product
     s += (float)a + bg[px * 4 + c] * (float)m;
   }
-  pooled[i] = s * (1.0f / 64.0f);
+  pooled[i] = s / (float)strip;
 }
 
 __global__ void corrmap_pass1(const int4* __restrict__ ids, const float* __restrict__ mask, int n, int sprite, int material, int chk_s,
@@ -609,11 +610,17 @@ extern "C" int sr_adain(const float* content, int64_t c_ps, int64_t c_cs, int64_
 
 extern "C" int sr_noise_pool(const void* noise_f16, const void* alpha_f16, const float* bg, float* pooled, float* out, int32_t H,
                              int32_t W, float* stats, void* stream) {
-  if (!noise_f16 || !alpha_f16 || !bg || !pooled || !out) SR_FAIL(SR_ERR_INVALID, "sr_noise_pool: null");
   if (H % 8 || W % 8 || (H * W) % 64) SR_FAIL(SR_ERR_INVALID, "sr_noise_pool: H,W must be multiples of 8");
+  return sr_noise_pool_strips(noise_f16, alpha_f16, bg, pooled, out, H, W, 64, stats, stream);
+}
+
+extern "C" int sr_noise_pool_strips(const void* noise_f16, const void* alpha_f16, const float* bg, float* pooled, float* out, int32_t H,
+                                    int32_t W, int32_t strip, float* stats, void* stream) {
+  if (!noise_f16 || !alpha_f16 || !bg || !pooled || !out) SR_FAIL(SR_ERR_INVALID, "sr_noise_pool: null");
+  if (strip < 1 || ((int64_t)H * W) % strip) SR_FAIL(SR_ERR_INVALID, "sr_noise_pool: %d x %d pixels are not whole strips of %d", H, W, strip);
   hipStream_t st = sr_stream(stream);
-  const int ng = H * W / 64;
-  hipLaunchKernelGGL(noise_pool_kernel, g1((int64_t)ng * 4), dim3(256), 0, st, (const _Float16*)noise_f16, (const _Float16*)alpha_f16, bg, pooled, ng);
+  const int ng = H * W / strip;
+  hipLaunchKernelGGL(noise_pool_kernel, g1((int64_t)ng * 4), dim3(256), 0, st, (const _Float16*)noise_f16, (const _Float16*)alpha_f16, bg, pooled, ng, strip);
   // AdaIN(content = pooled NHWC (1,h,w,4), style = full-res fp16 noise NHWC) -> (1,4,h,w)
   if (stats) {                                              // scratch of 2*256*4 floats: style statistics computed chip-wide
     constexpr int NBLK = 256;

@@ -192,12 +192,15 @@ class NoiseSequenceLoader(StableRenderingNode):
         unit = 64 if sd_version == "SD15" else 128
         if height % unit != 0 or width % unit != 0:
             raise ValueError(f"Noise shape for {sd_version} should be divisible by {unit}")
-        if height // unit != 8:
-            raise NotImplementedError("sr_noise_pool pools 64-pixel strips (512^2 SD1.5 / 1024^2 SDXL dumps)")
+        # reshape_magnitude = height // 64 (SD15) / height // 128 (SDXL): view(-1, m, m, 4).mean((1, 2)) averages m*m CONSECUTIVE
+        # pixels and the result is viewed (height / m, width / m) -- a 256^2 SD1.5 dump becomes a 64 x 64 latent (loaders.py:131-146)
+        m = height // unit
+        if (height * width) % (m * m) or width % m:
+            raise RuntimeError(f"shape '[-1, {m}, {m}, 4]' is invalid for input of size {noise.numel()}")      # what torch's view raises
         nz = noise.to(device=device, dtype=torch.float16).contiguous()
         zeros = torch.zeros(1, height, width, dtype=torch.float16, device=device)          # mask 0: the noise itself
         bg = torch.zeros(1, height, width, 4, dtype=torch.float32, device=device)
-        outs = [O.noise_pool(nz[i:i + 1], 1.0 - zeros, bg)[1] for i in range(nz.shape[0])]
+        outs = [O.noise_pool(nz[i:i + 1], 1.0 - zeros, bg, magnitude=m)[1] for i in range(nz.shape[0])]
         lat = torch.cat(outs, 0)
         return LATENT(samples=torch.zeros_like(lat), noise=lat)
 

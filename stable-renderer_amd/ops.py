@@ -525,15 +525,22 @@ def adain_nchw(content, style, eps=1e-5):
     return out
 
 
-def noise_pool(noise_f16, alpha_f16, bg_f32):
-    """(1,H,W,4) fp16, (1,H,W) fp16, (1,H,W,4) fp32 -> pooled (H/8,W/8,4) fp32, latent noise (1,4,H/8,W/8)"""
+def noise_pool(noise_f16, alpha_f16, bg_f32, magnitude=8):
+    """(1,H,W,4) fp16, (1,H,W) fp16, (1,H,W,4) fp32 -> pooled (H/m,W/m,4) fp32, latent noise (1,4,H/m,W/m): means of m*m
+    CONSECUTIVE pixels of the flattened image, as the reference's ``view(-1, m, m, 4).mean((1, 2))`` takes them (m = 8 in the
+    engine, renderManager.py:929-932; reshape_magnitude in NoiseSequenceLoader, _nodes/loaders.py:131-146), then AdaIN against the
+    full-resolution noise"""
     H, W = noise_f16.shape[1:3]
-    pooled = torch.empty(H // 8, W // 8, 4, dtype=torch.float32, device=noise_f16.device)
-    out = torch.empty(1, 4, H // 8, W // 8, dtype=torch.float32, device=noise_f16.device)
+    m = int(magnitude)
+    pooled = torch.empty(H // m, W // m, 4, dtype=torch.float32, device=noise_f16.device)
+    out = torch.empty(1, 4, H // m, W // m, dtype=torch.float32, device=noise_f16.device)
     key = ("np", str(noise_f16.device), getattr(_tls, "slot", 0))     # per in-flight slot: calls on other streams run this too
     if key not in _WS:
         _WS[key] = torch.empty(2048, dtype=torch.float32, device=noise_f16.device)
-    L.check(L.lib().sr_noise_pool(_p(noise_f16), _p(alpha_f16), _p(bg_f32), _p(pooled), _p(out), H, W, _p(_WS[key]), stream_ptr()))
+    if m == 8:
+        L.check(L.lib().sr_noise_pool(_p(noise_f16), _p(alpha_f16), _p(bg_f32), _p(pooled), _p(out), H, W, _p(_WS[key]), stream_ptr()))
+    else:
+        L.check(L.lib().sr_noise_pool_strips(_p(noise_f16), _p(alpha_f16), _p(bg_f32), _p(pooled), _p(out), H, W, m * m, _p(_WS[key]), stream_ptr()))
     return pooled, out
 
 

@@ -262,7 +262,7 @@ class DiffusionRunner:
         from . import conditioning as CD
         N, h, w = self.N, self.h, self.w
         C = self.unet.cfg["in_channels"]
-        pos, neg = CD.prepare(self._entries[0], self._entries[1], h, w)
+        pos, neg = CD.prepare(self._entries[0], self._entries[1], h, w, self.ms)
         sharded = self.shard is not None and self.shard.active
         if sharded:
             # a mask batch that follows the views of the WHOLE group (one mask per view) is cut to this rank's views; a single
@@ -276,27 +276,55 @@ class DiffusionRunner:
                     raise ValueError(f"a mask batch of {m.shape[0]} fits neither the group ({self.shard.n_views} views) nor this rank ({N})")
                 return e
             pos, neg = [own_views(e) for e in pos], [own_views(e) for e in neg]
-        groups = CD.groups_of(pos, neg, N, C, h, w, use_uncond=self.copies == 2)
-        dev = self.x.device
-        for g in groups:
-            ah, aw, _, _ = g["area"]
-            ch = len(g["members"])
-            g["chunks"] = ch
-            g["mult"] = torch.stack([m for _, _, m in g["members"]]).to(dev).contiguous()        # (chunks,N,C,ah,aw)
-            g["kinds"] = torch.tensor([k for k, _, _ in g["members"]], dtype=torch.int32, device=dev)
-            g["n_ctx"] = int(g["members"][0][1]["cond"].shape[1])
-        self._general = dict(groups=groups, built_for=None,
+        # entries with a sigma window (ConditioningSetTimestepRange) are skipped outside it (get_area_and_mult returns None,
+        # samplers.py:60-67), so the list of model calls depends on the step: one VARIANT (groups + plans) per distinct set of
+        # active entries, all of them built before the first step of a run (_general_plans)
+        self._general = dict(pos=pos, neg=neg, variants={}, groups=None, built_for=None,
                              out_c=torch.empty_like(self.x), cnt_c=torch.empty_like(self.x),
                              out_u=torch.empty_like(self.x), cnt_u=torch.empty_like(self.x))
         return self._general
 
-    def _general_plans(self, inject):
-        """build (once per injected-frame COUNT) and load the plans of the general path"""
+    def _general_key(self, sigma):
+        from . import conditioning as CD
+        G = self._general
+        return (tuple(CD.entry_active(e, sigma) for e in G["pos"]), tuple(CD.entry_active(e, sigma) for e in G["neg"]))
+
+    def _general_select(self, sigma):
+        """-> the groups (model calls) of the entries active at this sigma; G["groups"] points at them"""
+        from . import conditioning as CD
+        G = self._general
+        key = self._general_key(sigma)
+        if key not in G["variants"]:
+            N, h, w = self.N, self.h, self.w
+            C = self.unet.cfg["in_channels"]
+            pos = [e for e, on in zip(G["pos"], key[0]) if on]
+            neg = [e for e, on in zip(G["neg"], key[1]) if on]
+            groups = CD.groups_of(pos, neg, N, C, h, w, use_uncond=self.copies == 2)
+            dev = self.x.device
+            for g in groups:
+                g["chunks"] = len(g["members"])
+                g["mult"] = torch.stack([m for _, _, m in g["members"]]).to(dev).contiguous()        # (chunks,N,C,ah,aw)
+                g["kinds"] = torch.tensor([k for k, _, _ in g["members"]], dtype=torch.int32, device=dev)
+                g["n_ctx"] = int(g["members"][0][1]["cond"].shape[1])
+            G["variants"][key] = groups
+        G["groups"] = G["variants"][key]
+        return G["groups"]
+
+    def _general_plans(self, inject, sigmas=None):
+        """build (once per injected-frame COUNT) and load the plans of the general path: of every variant the run's sigmas select"""
         G = self._general
         sharded = self.shard is not None and self.shard.active
         key = None if inject is None else len(inject)
-        if G["built_for"] != ("built", key):
-            for g in G["groups"]:
+        first = G["groups"]
+        for sg in (sigmas if sigmas is not None else []):
+            self._general_select(float(sg))
+        if first is not None:
+            G["groups"] = first
+        all_groups = [g for v in G["variants"].values() for g in v]
+        if G["built_for"] != ("built", key) or any("plan" not in g for g in all_groups):
+            for g in all_groups:
+                if "plan" in g and G["built_for"] == ("built", key):
+                    continue
                 ah, aw, _, _ = g["area"]
                 B = self.N * g["chunks"]
                 control, inputs, cn = None, None, None
@@ -307,7 +335,7 @@ class DiffusionRunner:
                 g["plan"]["cn"] = cn
             G["built_for"] = ("built", key)
         self._inject_global = inject
-        for g in G["groups"]:
+        for g in all_groups:
             p, N = g["plan"], self.N
             if inject is not None:
                 B = (self.shard.n_views if sharded else N) * g["chunks"]      # the indices address the WHOLE group's batch of this call
@@ -347,6 +375,7 @@ class DiffusionRunner:
     def _general_denoise(self, sigma, timestep_index, want_d):
         """one sampling_function call (samplers.py:323-358) over the prepared groups -> self.den (and self.d)"""
         G = self._general
+        self._general_select(sigma)
         G["out_c"].zero_()
         G["out_u"].zero_()
         G["cnt_c"].fill_(1e-37)
@@ -507,6 +536,12 @@ class DiffusionRunner:
             if general:
                 n_rand_ = inject_n_rand if (inject_n_rand is not None and inject_n_rand >= 0) else None
                 G = self._general if self._general is not None else self._build_general(n_rand_)
+                # the model calls of the first step that HAS active entries: pre_atten_inject draws its indices on the run's first
+                # UNet call, from that call's batch (corresponder.py:204-205)
+                first_groups = next((gr for gr in (self._general_select(float(v)) for v in sig[:-1]) if gr), None)
+                if first_groups is None:
+                    raise ValueError("no conditioning entry is active at any step of the schedule")
+                G["groups"] = first_groups
             inject = None
             if inject_n_rand is not None and inject_n_rand >= 0:
                 n_all = self.N if self.shard is None else self.shard.n_views
@@ -529,7 +564,7 @@ class DiffusionRunner:
         self.x.copy_(noise.to(dev, torch.float32))
         O.axpby(self.x, latent.to(dev, torch.float32).contiguous(), 1.0, s0)        # x = noise*s0 + latent
         if general:
-            self._general_plans(inject)
+            self._general_plans(inject, [float(v) for v in sig[:-1]])
             p = G["groups"][0]["plan"]
         else:
             p = self._ensure_plan(inject)
@@ -563,7 +598,7 @@ class DiffusionRunner:
         out = torch.empty_like(self.x)
         out.zero_()
         O.axpby(out, self.x, 1.0 / self.latent_scale, 0.0)
-        run_plans = [g["plan"] for g in G["groups"]] if general else [p]
+        run_plans = [g["plan"] for v in G["variants"].values() for g in v] if general else [p]
         flags = [q["inject_err"] for q in run_plans if q.get("inject_err") is not None]
         if flags and int(torch.stack([f.reshape(()) for f in flags]).max().item()) != 0:      # the run's one host sync (results are due anyway)
             for f in flags:

@@ -332,10 +332,14 @@ def _cond_lists(ctx_dim, H, W):
         "areas": ([[c(4), {}], [c(5), {"area": ("percentage", 0.5, 0.5, 0.25, 0.25), "strength": 0.9}],
                    [c(6), {"mask": box, "mask_strength": 1.0, "set_area_to_bounds": True}]], [[c(7), {}], [c(8), {"strength": 0.5}]], 4.0),
         "cfg1": ([[c(9), {}], [c(10), {"mask": blob, "mask_strength": 1.0, "set_area_to_bounds": False}]], [[c(11), {}]], 1.0),
+        # ConditioningSetTimestepRange (comfyUI/nodes.py:270-285): the second prompt acts in the middle of the schedule only, the
+        # negative prompt until 60 % of it -- entries outside their sigma window are not run (samplers.py:60-67), so the model
+        # calls change from step to step (B = 2N, 3N, 2N, N over the 8 steps)
+        "ranges": ([[c(12), {}], [c(13), {"start_percent": 0.3, "end_percent": 0.7, "strength": 0.8}]], [[c(14), {"end_percent": 0.6}]], 5.0),
     }
 
 
-@pytest.mark.parametrize("case", ["masks_and_strengths", "areas", "cfg1"])
+@pytest.mark.parametrize("case", ["masks_and_strengths", "areas", "cfg1", "ranges"])
 def test_conditioning_lists_with_masks_and_areas_vs_oracle(case):
     """calc_cond_uncond_batch's composition on the HIP path (sr_cond_crop_scale / sr_cond_accumulate / sr_cfg_combine + one UNet
     plan per model-call shape) against the oracle, whose composition arithmetic is pinned to the reference by the toy-model golden
@@ -352,19 +356,22 @@ def test_conditioning_lists_with_masks_and_areas_vs_oracle(case):
     noise = torch.randn(N, 4, h, w, generator=torch.Generator().manual_seed(21))
     run = DiffusionRunner(net, N, h, w, scale, n_ctx=77, use_graph=False)
     run.set_cond_entries(entries_of(pos), entries_of(neg))
+    steps = 8 if case == "ranges" else 3
     torch.manual_seed(3)
-    out, _ = run.sample(noise, 3, "euler", "normal")
+    out, _ = run.sample(noise, steps, "euler", "normal")
     torch.cuda.synchronize()
+    if case == "ranges":                                       # the sigma windows really cut the schedule into different model calls
+        assert len({k for k in run._general["variants"]}) >= 3
     torch.manual_seed(3)
     with torch.no_grad():
-        ref, _ = ORC.sample_frames(sd, cfg, noise, None, None, None, 3, scale, "euler", "normal",
+        ref, _ = ORC.sample_frames(sd, cfg, noise, None, None, None, steps, scale, "euler", "normal",
                                    cond_entries=(entries_of(pos), entries_of(neg)))
     err = (out.cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
     assert err < 2e-3, (case, err)
     # the composition matters: the plain [neg | pos] run of the first entries gives a different latent
     run.set_conditioning(pos[0][0], neg[0][0])
     torch.manual_seed(3)
-    plain, _ = run.sample(noise, 3, "euler", "normal")
+    plain, _ = run.sample(noise, steps, "euler", "normal")
     assert (plain.cpu() - ref).abs().max().item() > 1e-2
 
 

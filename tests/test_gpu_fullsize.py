@@ -108,7 +108,12 @@ def _run(gold, make_scene, dtype, corresponder_fn, controls=None, unet_cfg=None,
     return out
 
 
-def _check(tag, gold, r32, r16, fp16_floor, rel32_max=5e-3):
+# fp16 floors = what the GPU runs measure minus 6 dB (fp16 is the dtype of every bench number: a kernel change that costs more than
+# that fails here); fp32: the north_star's 40 dB and a latent relative error of 1e-3 (measured 1.2e-5 .. 6e-5)
+FLOOR16 = {"bench8": 50.0, "bench8_20": 40.0, "config2": 54.0, "config3": 49.0, "config4": 50.0}
+
+
+def _check(tag, gold, r32, r16, fp16_floor, rel32_max=1e-3):
     ref_s, ref_img = T(gold["samples"]), T(gold["img_sub"]).float()
     p32, p16 = psnr(r32[1][:, ::4, ::4], ref_img), psnr(r16[1][:, ::4, ::4], ref_img)
     rel32 = (r32[0] - ref_s).abs().max().item() / ref_s.abs().max().item()
@@ -132,7 +137,21 @@ def test_bench_shape_eight_overlapped_views_vs_reference():
     r32 = _run(g, mk, torch.float32, _overlap)
     r16 = _run(g, mk, torch.float16, _overlap)
     assert r32[2] == g["inj"].tolist() and r16[2] == g["inj"].tolist()          # same random frame drawn from the global generator
-    _check("bench shape (8 views, 512^2, ddim/normal cfg 8, 3 steps, B=16 evaluations)", g, r32, r16, 25.0)
+    _check("bench shape (8 views, 512^2, ddim/normal cfg 8, 3 steps, B=16 evaluations)", g, r32, r16, FLOOR16["bench8"])
+
+
+@pytest.mark.timeout(900)
+def test_headline_workload_eight_views_twenty_steps_vs_reference():
+    """the bench workload at its headline length: 8 overlapped views x 20 ddim steps (B = 16 evaluations, overlap active on the steps
+    above timestep 500), error compounding over 20 evaluations under the tuner's per-M tiles -- against the reference's own run
+    (oracle/gen_golden_full.py bench8_20: 24 minutes of container CPU)"""
+    from stable_renderer_amd.pipeline import BakeBallScene
+    g = np.load(os.path.join(GOLD, "full_bench8_20.npz"))
+    mk = lambda: BakeBallScene(512, 512, k=6)
+    r32 = _run(g, mk, torch.float32, _overlap)
+    r16 = _run(g, mk, torch.float16, _overlap)
+    assert r32[2] == g["inj"].tolist() and r16[2] == g["inj"].tolist()
+    _check("headline workload (8 views, 512^2, ddim/normal cfg 8, 20 steps, B=16 evaluations)", g, r32, r16, FLOOR16["bench8_20"])
 
 
 @pytest.mark.timeout(900)
@@ -143,7 +162,7 @@ def test_config2_bake_ball_512_20_steps_vs_reference():
     mk = lambda: BakeBallScene(512, 512, k=6)
     r32 = _run(g, mk, torch.float32, DefaultCorresponder)
     r16 = _run(g, mk, torch.float16, DefaultCorresponder)
-    _check("config 2 (512^2, 20 steps, 1 view, euler/normal cfg 8)", g, r32, r16, 25.0)
+    _check("config 2 (512^2, 20 steps, 1 view, euler/normal cfg 8)", g, r32, r16, FLOOR16["config2"])
 
 
 @pytest.mark.timeout(900)
@@ -154,7 +173,7 @@ def test_config3_boat_mesh_two_overlapped_views_512_20_steps_vs_reference():
     r32 = _run(g, mk, torch.float32, _overlap)
     r16 = _run(g, mk, torch.float16, _overlap)
     assert r32[2] == g["inj"].tolist() and r16[2] == g["inj"].tolist()
-    _check("config 3 (boat-like mesh, 512^2, 20 steps, 2 overlapped views, ddim/normal cfg 8)", g, r32, r16, 20.0)
+    _check("config 3 (boat-like mesh, 512^2, 20 steps, 2 overlapped views, ddim/normal cfg 8)", g, r32, r16, FLOOR16["config3"])
 
 
 @pytest.mark.timeout(900)
@@ -177,7 +196,7 @@ def test_config4_two_full_width_controlnets_512_vs_reference():
                 for pl, s, st in zip(m["planes"], m["cn_seeds"], m["strengths"])]
     r32 = _run(g, mk, torch.float32, DefaultCorresponder, controls=controls(torch.float32), planes_sha=bytes(g["nd_sha"]).decode())
     r16 = _run(g, mk, torch.float16, DefaultCorresponder, controls=controls(torch.float16))
-    _check("config 4 (SD1.5 UNet + 2 full-width ControlNets, 512^2, 2 views, euler/normal cfg 8, 3 steps)", g, r32, r16, 25.0)
+    _check("config 4 (SD1.5 UNet + 2 full-width ControlNets, 512^2, 2 views, euler/normal cfg 8, 3 steps)", g, r32, r16, FLOOR16["config4"])
     plain = T(g["samples_plain"])                                # the reference's run WITHOUT the nets: they must matter
     assert (T(g["samples"]) - plain).abs().max() > 50 * (r32[0] - T(g["samples"])).abs().max()
 

@@ -260,6 +260,33 @@ def test_cond_composition_vs_reference(gold):
         assert torch.allclose(r, T(d[f"{name}_cfg"]), atol=1e-5, rtol=1e-6), name
 
 
+def test_cond_timestep_ranges_vs_reference(gold):
+    """ConditioningSetTimestepRange windows: calculate_start_end_timesteps + get_area_and_mult's sigma test (comfy/samplers.py:60-67,
+    578-602) -- the reference's sampling_function at sigmas inside / outside the windows (golden cond_ranges.npz), the oracle's
+    restatement and the product's host-side window arithmetic (conditioning.with_timestep_ranges / entry_active)"""
+    from stable_renderer_amd import conditioning as CD
+    from stable_renderer_amd.sampling import ModelSamplingDiscrete
+    d = gold("cond_ranges")
+    x, scale = T(d["x"]), float(d["scale"])
+    pos = [dict(cond=T(d["pos0_c"])), dict(cond=T(d["pos1_c"]), start_percent=0.3, end_percent=0.7, strength=0.8)]
+    neg = [dict(cond=T(d["neg0_c"]), start_percent=0.0, end_percent=0.5)]
+    ms = O.ModelSampling()
+    p, n = O.prepare_cond_entries(pos, neg, 16, 24, ms)
+    win = [[e.get("timestep_start", -1.0), e.get("timestep_end", -1.0)] for e in p + n]
+    assert np.allclose(np.array(win), d["windows"], rtol=1e-6)
+    p2, n2 = CD.prepare(pos, neg, 16, 24, ModelSamplingDiscrete())                  # the product's host arithmetic: same windows
+    assert np.allclose(np.array([[e.get("timestep_start", -1.0), e.get("timestep_end", -1.0)] for e in p2 + n2]), d["windows"], rtol=1e-6)
+    seen = set()
+    for i, sg in enumerate(d["sigmas"].tolist()):
+        r = O.sampling_function(toy_model, x, torch.tensor([sg, sg]), n, p, scale)
+        assert torch.allclose(r, T(d[f"cfg_{i}"]), atol=1e-5, rtol=1e-6), sg
+        act = tuple(O.entry_active(e, sg) for e in p + n)
+        assert act == tuple(CD.entry_active(e, sg) for e in p2 + n2)
+        seen.add(act)
+    assert len(seen) >= 4                                                          # the sigmas exercise four different active sets
+    assert not CD.is_plain([dict(cond=x, end_percent=0.5)]) and CD.is_plain([dict(cond=x, start_percent=0.0, end_percent=1.0)])
+
+
 def test_vae_encoder_vs_reference(gold):
     """Encoder + quant_conv + posterior sample (VAE.encode, sd.py:353-371) against the reference AutoencoderKL"""
     d = gold("vae_enc")
