@@ -195,9 +195,13 @@ def main():
                          "(strong scaling; the replica figure is measured after it and printed beside it as `replicas`); "
                          "replica (default on one GPU): every GPU bakes its own 8-view group (weak scaling, no collective)")
     ap.add_argument("--no-replicas-beside", action="store_true", help="shard mode: skip the replica measurement that follows it")
-    ap.add_argument("--shard-inflight", action="store_true",
-                    help="shard mode: --inflight K sharded calls in flight per rank, every slot with its own process group "
-                         "(opt-in: rehearsed with gloo and a one-rank RCCL group only)")
+    ap.add_argument("--shard-inflight", action="store_true", default=None,
+                    help="shard mode: --inflight K sharded calls in flight per rank, every slot with its own process group.  Default "
+                         "ON in the forced one-rank rehearsal (SR_SHARD_FORCE=1 with one rank: what it exercises -- several RCCL "
+                         "communicators in flight on one GPU -- is what 2-rank gloo and one-rank RCCL tests cover), opt-in with more "
+                         "than one rank: whether RCCL's kernels of several communicators co-schedule on every GPU of a node is "
+                         "something only a node can show")
+    ap.add_argument("--no-shard-inflight", dest="shard_inflight", action="store_false")
     ap.add_argument("--workload", default="sd15-512", choices=["sd15-512", "sdxl-1024"],
                     help="sd15-512: the configuration BASELINE.json's metric is quoted on (default); sdxl-1024: BASELINE config 5, "
                          "the SDXL base UNet (2.57 B parameters) at 1024x1024 through the same raster / overlap / K-V injection / "
@@ -216,6 +220,8 @@ def main():
         print("bench.py: --gpus %d ignored, the launcher set WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
     if a.mode is None:
         a.mode = "shard" if world > 1 else "replica"
+    if a.shard_inflight is None:
+        a.shard_inflight = world == 1 and os.environ.get("SR_SHARD_FORCE") == "1"
     if a.mode == "shard" and a.views % world:
         sys.exit("bench.py: %d views do not split over %d ranks (--mode shard needs views %% ranks == 0; --mode replica has no such "
                  "constraint)" % (a.views, world))

@@ -135,6 +135,8 @@ def export_unet(path, unet, built):
         io["y"] = (built["y"], False)
     if built.get("inject") is not None:
         io["inject"] = (built["inject"], False)
+    if built.get("inject_err") is not None:                 # the device flag an out-of-range injected index raises (sr_gather_rows)
+        io["inject_err"] = (built["inject_err"], True)
     return export_bundle(path, {"prologue": built["prologue"], "step": built["step"]}, io, constants=list(unet.w.values()))
 
 

@@ -15,6 +15,9 @@ class ControlNet:
     def __init__(self, state_dict, cfg=None, dtype=torch.float16, device="cuda", strength=1.0):
         self.cfg = dict(SD15_CFG if cfg is None else cfg)
         self.dtype, self.device, self.strength = dtype, torch.device(device), float(strength)
+        # ControlBase.timestep_percent_range (comfy/controlnet.py:41-62, set by ControlNetApplyAdvanced): outside the sigma window
+        # [percent_to_sigma(end), percent_to_sigma(start)] get_control returns only the previous nets' residuals (:184-189)
+        self.timestep_percent_range = (0.0, 1.0)
         self.ke = O.kelems(dtype)
         hint_layers = tuple(f"input_hint_block.{i}" for i, _ in HINT_CONVS)
         self.w, self.shapes = pack_weights(state_dict, dtype, self.device, pad_cin=("input_blocks.0.0",), pad_cout=hint_layers[:-1])

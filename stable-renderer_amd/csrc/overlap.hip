@@ -33,21 +33,32 @@ __global__ void overlap_build1(const int4* __restrict__ ids, int N, int H, int W
                                int* __restrict__ cell_win, int* __restrict__ info) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)N * H * W;
-  if (i >= total) return;
-  const int4 v = ids[i];
-  int cell = -1;
-  if (id_valid(v)) {
-    const int x = (int)(i % W), y = (int)((i / W) % H), f = (int)(i / ((int64_t)W * H));
-    bool ok;
-    cell = cell_of(f, y, x, H, W, lh, lw, &ok);
-    if (!ok || v.w < 0) { atomicOr(&info[1], 1); cell = -1; }
-    else {
-      atomicMax(&cell_win[cell], (int)i);                  // last (f,y,x) pixel of the cell wins the scatter
-      atomicMax(&info[0], v.w);
-      atomicAdd(&info[2], 1);
+  // the two scalars every valid pixel contributes to (largest vertex id, number of valid pixels) are reduced across the wave first:
+  // with one atomic per PIXEL on these two addresses the kernel ran 632 us per 8 x 512^2 call (2 x 1.5 M serialised L2 atomics;
+  // profiles/r03_bench_kernel_stats.csv) for 33.5 MB of ids -- 100x its HBM time
+  int vmax = -1, valid = 0;
+  if (i < total) {
+    const int4 v = ids[i];
+    int cell = -1;
+    if (id_valid(v)) {
+      const int x = (int)(i % W), y = (int)((i / W) % H), f = (int)(i / ((int64_t)W * H));
+      bool ok;
+      cell = cell_of(f, y, x, H, W, lh, lw, &ok);
+      if (!ok || v.w < 0) { atomicOr(&info[1], 1); cell = -1; }
+      else {
+        atomicMax(&cell_win[cell], (int)i);                // last (f,y,x) pixel of the cell wins the scatter
+        vmax = v.w;
+        valid = 1;
+      }
     }
+    pix_cell[i] = cell;
   }
-  pix_cell[i] = cell;
+  const int nvalid = __popcll(__ballot(valid));
+  for (int o = 32; o >= 1; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o));
+  if ((threadIdx.x & 63) == 0 && nvalid > 0) {
+    atomicMax(&info[0], vmax);
+    atomicAdd(&info[2], nvalid);
+  }
 }
 __global__ void overlap_build2(const int4* __restrict__ ids, int ncell, const int* __restrict__ cell_win, int* __restrict__ cell_vid) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;

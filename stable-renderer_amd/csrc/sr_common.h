@@ -72,13 +72,13 @@ __device__ __forceinline__ void sr_glds16_asm_saddr(unsigned voff, const void* s
 // s_waitcnt vmcnt(N) that follows also covers them (requests retire in issue order).
 __device__ __forceinline__ void sr_prefetch_touch(const void* base, int64_t bytes, int64_t gtid, int64_t gthreads, unsigned lds_scratch_wave) {
   const int64_t n = bytes >> 6;                              // 64-byte sectors
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0" : "=&s"(keep) : "s"(lds_scratch_wave));
+  const unsigned keep = sr_m0_save();
   for (int64_t i = gtid; i < n; i += gthreads) {
     const char* src = (const char*)base + (i << 6);
-    asm volatile("global_load_lds_dword %0, off" ::"v"(src) : "memory");
+    // M0 is set in the SAME statement as the load that reads it: between two asm statements the compiler may use M0 itself
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds_scratch_wave) : "memory");
   }
-  asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
+  sr_m0_restore(keep);
 }
 __device__ __forceinline__ unsigned sr_lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;

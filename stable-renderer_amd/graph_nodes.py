@@ -225,8 +225,9 @@ class AppliedControl:
     """What ControlNetApply leaves in the conditioning: ``control_net.copy().set_cond_hint(hint, strength)`` chained through
     ``previous_controlnet`` (comfy/controlnet.py:37-93)"""
 
-    def __init__(self, net, hint, strength, previous=None):
+    def __init__(self, net, hint, strength, previous=None, timestep_percent_range=(0.0, 1.0)):
         self.net, self.hint, self.strength, self.previous = net, hint, float(strength), previous
+        self.timestep_percent_range = (float(timestep_percent_range[0]), float(timestep_percent_range[1]))
 
     def chain(self):
         c, out = self, []
@@ -262,6 +263,40 @@ class ControlNetApply:
             d["control_apply_to_uncond"] = True
             out.append([t[0], d])
         return (out,)
+
+
+class ControlNetApplyAdvanced:
+    """comfyUI/nodes.py:850-896: the net goes on BOTH conditionings, with a start / end percent of the schedule outside which it is
+    not run (set_cond_hint(hint, strength, (start_percent, end_percent)), comfy/controlnet.py:53-62, 184-189)"""
+    RETURN_TYPES = ("CONDITIONING", "CONDITIONING")
+    RETURN_NAMES = ("positive", "negative")
+    FUNCTION = "apply_controlnet"
+    CATEGORY = "conditioning"
+
+    @classmethod
+    def INPUT_TYPES(s):
+        return {"required": {"positive": ("CONDITIONING",), "negative": ("CONDITIONING",), "control_net": ("CONTROL_NET",),
+                             "image": ("IMAGE",), "strength": ("FLOAT", {"default": 1.0, "min": 0.0, "max": 10.0, "step": 0.01}),
+                             "start_percent": ("FLOAT", {"default": 0.0, "min": 0.0, "max": 1.0, "step": 0.001}),
+                             "end_percent": ("FLOAT", {"default": 1.0, "min": 0.0, "max": 1.0, "step": 0.001})}}
+
+    def apply_controlnet(self, positive, negative, control_net, image, strength, start_percent, end_percent):
+        if strength == 0:
+            return (positive, negative)
+        hint = image.movedim(-1, 1)
+        made, out = {}, []
+        for conditioning in (positive, negative):
+            c = []
+            for t in conditioning:
+                d = dict(t[1])
+                prev = d.get("control")
+                if id(prev) not in made:
+                    made[id(prev)] = AppliedControl(control_net, hint, strength, prev, (start_percent, end_percent))
+                d["control"] = made[id(prev)]
+                d["control_apply_to_uncond"] = False
+                c.append([t[0], d])
+            out.append(c)
+        return (out[0], out[1])
 
 
 # ---- sampling / decode ---------------------------------------------------------------------------------------------------
@@ -396,7 +431,7 @@ class IfValTypeEqual(N.StableRenderingNode):
 
 
 for _name, _cls in (("CheckpointLoaderSimple", CheckpointLoaderSimple), ("LoraLoaderModelOnly", LoraLoaderModelOnly),
-                    ("ControlNetLoader", ControlNetLoader), ("ControlNetApply", ControlNetApply), ("CLIPTextEncode", CLIPTextEncode),
+                    ("ControlNetLoader", ControlNetLoader), ("ControlNetApply", ControlNetApply), ("ControlNetApplyAdvanced", ControlNetApplyAdvanced), ("CLIPTextEncode", CLIPTextEncode),
                     ("SceneTextEncode", SceneTextEncode), ("MaskedTextEncode", MaskedTextEncode), ("KSampler", KSampler), ("VAEDecode", VAEDecode), ("VAEEncode", VAEEncode), ("LoadImage", LoadImage),
                     ("IsNotNone", IsNotNone), ("If", If), ("IfValTypeEqual", IfValTypeEqual),
                     ("EngineData", N.EngineDataNode), ("VirtualEngineData", N.VirtualEngineDataNode),

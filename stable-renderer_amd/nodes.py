@@ -284,12 +284,16 @@ def custom_ksampler(model: MODEL, seed, steps, cfg, sampler_name, scheduler, pos
     nets = []
     for c in controls:
         net = c.net
-        if net.strength != c.strength:                 # same packed weights, its own strength (set_cond_hint(hint, strength))
+        rng = getattr(c, "timestep_percent_range", (0.0, 1.0))
+        if net.strength != c.strength or tuple(getattr(net, "timestep_percent_range", (0.0, 1.0))) != tuple(rng):
+            # same packed weights, its own strength / schedule window (set_cond_hint(hint, strength, timestep_percent_range))
             cache = net.__dict__.setdefault("_by_strength", {})
-            if c.strength not in cache:
-                cache[c.strength] = copy.copy(net)
-                cache[c.strength].strength = c.strength
-            net = cache[c.strength]
+            key = (c.strength, tuple(rng))
+            if key not in cache:
+                cache[key] = copy.copy(net)
+                cache[key].strength = c.strength
+                cache[key].timestep_percent_range = tuple(rng)
+            net = cache[key]
         nets.append(net)
     run = model.runner(N, h, w, cfg, controlnets=nets)
     run.set_cond_entries(positive, negative)

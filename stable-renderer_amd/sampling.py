@@ -225,6 +225,27 @@ class DiffusionRunner:
                 mid = cp["middle"]
         return dict(output=outs, middle=mid), inputs, dict(plans=cps, merge=pb.take())
 
+    def _run_controls(self, p, sigma):
+        """the ControlNet encoders of one model call, then the plan that sums their residuals.  A net outside its sigma window
+        (ControlNetApplyAdvanced's start / end percent -> ControlBase.timestep_range, comfy/controlnet.py:53-62) is not run:
+        get_control then returns the previous nets' residuals alone (:184-189) -- here its residual buffers are zeroed once on
+        leaving the window, so the merge adds nothing for it"""
+        from . import conditioning as CD
+        for net, cp in zip(self.controlnets, p["cn"]["plans"]):
+            lo, hi = getattr(net, "timestep_percent_range", (0.0, 1.0))
+            active = True
+            if (lo, hi) != (0.0, 1.0):
+                active = not (sigma > CD.percent_to_sigma(self.ms, lo) or sigma < CD.percent_to_sigma(self.ms, hi))
+            if active:
+                cp["step"].run()
+                cp["_zeroed"] = False
+            elif not cp.get("_zeroed"):
+                for t in list(cp["output"]) + [cp["middle"]]:
+                    if t is not None:
+                        t.zero_()
+                cp["_zeroed"] = True
+        p["cn"]["merge"].run()
+
     def set_control_hints(self, hints):
         """hints: one (N,3,8h,8w) tensor in [0,1] per ControlNet (ControlNetApply's image.movedim(-1,1), nodes.py:745-760);
         the same hint serves the cond and uncond halves of the batch"""
@@ -282,6 +303,7 @@ class DiffusionRunner:
         self._general = dict(pos=pos, neg=neg, variants={}, groups=None, built_for=None,
                              out_c=torch.empty_like(self.x), cnt_c=torch.empty_like(self.x),
                              out_u=torch.empty_like(self.x), cnt_u=torch.empty_like(self.x))
+        self._general_select(float(self.ms.sigma_max))        # (G["groups"]: the model calls at the top of the schedule)
         return self._general
 
     def _general_key(self, sigma):
@@ -385,9 +407,7 @@ class DiffusionRunner:
             O.cond_crop_scale(self.x, p["x"], g["area"], g["chunks"], sigma)
             p["t"].fill_(float(timestep_index))
             if p.get("cn") is not None:
-                for cp in p["cn"]["plans"]:
-                    cp["step"].run()
-                p["cn"]["merge"].run()
+                self._run_controls(p, sigma)
             if p["schedule"]:                                # view-sharded group: segments + K/V-source broadcasts
                 self._sharded_eval(p, chunks=g["chunks"])
             else:
@@ -434,9 +454,7 @@ class DiffusionRunner:
         O.eps_scale_input(self.x, p["x"], self.copies, sigma)
         p["t"].fill_(float(timestep_index))
         if p.get("cn") is not None:                         # ControlNet encoders on the same (x, t, ctx), then their merge; no
-            for cp in p["cn"]["plans"]:                     # cross-view work inside them (controlnet.py:205-213 passes no corresponder)
-                cp["step"].run()
-            p["cn"]["merge"].run()
+            self._run_controls(p, sigma)                    # cross-view work inside them (controlnet.py:205-213 passes no corresponder)
         if p["schedule"]:
             return self._sharded_eval(p)
         if self.use_graph:

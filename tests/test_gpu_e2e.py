@@ -209,6 +209,70 @@ def test_sampling_with_two_controlnets_vs_oracle():
     assert (o2.cpu() - ref).abs().max().item() > 1e-2
 
 
+def test_controlnets_with_sigma_windows_vs_oracle():
+    """ControlNetApplyAdvanced's start / end percent (ControlBase.timestep_percent_range -> timestep_range, comfy/controlnet.py:
+    41-62): a net outside its sigma window contributes nothing at that step -- get_control returns the previous nets' residuals
+    alone (:184-189).  Net 1 acts from 35 % of the schedule on, net 2 until 55 %: over the 8 steps the UNet sees net 2 alone, both,
+    then net 1 alone.  Oracle: the same composition from its pinned pieces, each net's residuals dropped outside its window."""
+    import sr_oracle as ORC
+    from stable_renderer_amd.unet import UNet, SD15_CFG
+    from stable_renderer_amd.controlnet import ControlNet
+    from stable_renderer_amd.sampling import DiffusionRunner
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    sd_u = _sd("unet_tiny_keys.json", 1)
+    sds = (_sd("controlnet_tiny_keys.json", 5), _sd("controlnet_tiny_keys.json", 6))
+    g = torch.Generator().manual_seed(18)
+    N, h, w, steps, cfg_scale = 2, 16, 16, 8, 3.0
+    noise = torch.randn(N, 4, h, w, generator=g)
+    pos, neg = torch.randn(1, 77, 64, generator=g), torch.randn(1, 77, 64, generator=g)
+    hints = [torch.rand(N, 3, 8 * h, 8 * w, generator=g), torch.rand(N, 3, 8 * h, 8 * w, generator=g)]
+    strengths, ranges = (0.8, 0.6), ((0.35, 1.0), (0.0, 0.55))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ms = ORC.ModelSampling()
+    sig, _ = ORC.ksampler_sigmas(ms, "normal", steps, None)
+    x0 = noise * torch.sqrt(1.0 + sig[0] ** 2.0)
+    windows = [(ORC.percent_to_sigma(ms, a), ORC.percent_to_sigma(ms, b)) for a, b in ranges]
+    seen = []
+
+    def denoise_fn(xx, sigma):
+        xin, s2 = torch.cat([xx, xx]), torch.cat([sigma, sigma])
+        c = torch.cat([neg.expand(N, -1, -1), pos.expand(N, -1, -1)])
+        t = ms.timestep(s2).float()
+        xc = ORC.eps_input(xin, s2)
+        on = [not (float(sigma[0]) > st or float(sigma[0]) < en) for st, en in windows]      # controlnet.py:184-185
+        seen.append(tuple(on))
+        ctrls = [ORC.controlnet_forward(sd, cfg, xc, torch.cat([hh, hh]), t, c, strength=sg)
+                 for sd, hh, sg, a in zip(sds, hints, strengths, on) if a]
+        merged = None
+        if ctrls:
+            merged = {"output": [sum(parts) for parts in zip(*[cc["output"] for cc in ctrls])],
+                      "middle": [sum(cc["middle"][0] for cc in ctrls)]}
+        den = ORC.eps_denoised(xin, ORC.unet_forward(sd_u, cfg, xc, t, c, control=merged), s2)
+        return den[:N] + (den[N:] - den[:N]) * cfg_scale
+    with torch.no_grad():
+        ref = ORC.sample_loop(denoise_fn, x0.clone(), sig, "euler", None) / 0.18215
+    assert len(set(seen)) == 3 and (True, True) in seen                   # net 2 alone, both, net 1 alone
+    net = UNet(sd_u, cfg, dtype=torch.float32)
+    cns = [ControlNet(sd, cfg, dtype=torch.float32, strength=sg) for sd, sg in zip(sds, strengths)]
+    for cn, r in zip(cns, ranges):
+        cn.timestep_percent_range = r
+    for use_graph in (False, True):
+        run = DiffusionRunner(net, N, h, w, cfg_scale, use_graph=use_graph, controlnets=cns)
+        run.set_conditioning(pos, neg)
+        run.set_control_hints(hints)
+        out, _ = run.sample(noise, steps, "euler", "normal", seed=0)
+        torch.cuda.synchronize()
+        err = (out.cpu() - ref).abs().max().item()
+        assert err < 2e-3 * max(1.0, ref.abs().max().item()), (use_graph, err)
+    for cn in cns:                                                          # without the windows the result is a different one
+        cn.timestep_percent_range = (0.0, 1.0)
+    run = DiffusionRunner(net, N, h, w, cfg_scale, use_graph=False, controlnets=cns)
+    run.set_conditioning(pos, neg)
+    run.set_control_hints(hints)
+    o2, _ = run.sample(noise, steps, "euler", "normal", seed=0)
+    assert (o2.cpu() - ref).abs().max().item() > 1e-2
+
+
 def test_pipeline_with_gbuffer_driven_controlnets():
     """config 4 wiring: depth + normal ControlNets fed by the G-buffer planes of the same views (reference
     resources/example-workflows/miku-control.json: EngineData.depth_maps / normal_maps -> ControlNetApply x2)"""
