@@ -115,4 +115,4 @@ def test_config1_from_the_references_own_dumps_through_the_loader_nodes(tmp_path
     rel32 = (res[torch.float32][0] - ref_s).abs().max().item() / ref_s.abs().max().item()
     print(f"config 1 from the reference's dumps: PSNR vs the reference fp32 {p32:.1f} dB / fp16 {p16:.1f} dB, latent rel err fp32 {rel32:.2e}")
     assert p32 >= 40.0 and rel32 < 1e-3, (p32, rel32)
-    assert p16 >= 50.0, p16
+    assert p16 >= 58.0, p16                                    # measured 64.8 dB
