@@ -100,6 +100,9 @@ __device__ __forceinline__ float sr_gelu_f(float x) {
   return x * cdf;
 }
 
+// (A polynomial erf without v_rcp / v_exp for the fp16 GEGLU epilogue -- degree 9 in u = 2 z^2 / 3.7^2 - 1, |GELU error| <= 1.8e-4 --
+//  was built and timed in round 4: 190.6 vs 194.3 us on the 64x64 GEGLU projection, 162.1 vs 159.6 and 137.1 vs 138.4 on the other
+//  two: noise.  The epilogue's cost is not the GELU arithmetic; the 1.5e-7 form above stays.)
 __device__ __forceinline__ float sr_load_f(const _Float16* p) { return (float)*p; }
 __device__ __forceinline__ float sr_load_f(const float* p) { return *p; }
 __device__ __forceinline__ void sr_store_f(_Float16* p, float v) { *p = (_Float16)v; }

@@ -5,14 +5,13 @@
 #   3. two --pmc passes (FETCH_SIZE, WRITE_SIZE; separate: together they exceed the TCC slots) of `bench.py --roofline-only`
 #      -> HBM-side bytes of the igemm family per UNet evaluation (tools/summarize_traffic.py)
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-export SR_AUTOTUNE_CACHE=$OUT/tune.json
+# (bench.py pins the tuner table itself since round 4: tests/golden/tune_table.json -- the profiled runs make no tuning launches)
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --roofline-only > $OUT/roofline_only_unprofiled.json 2> $OUT/roofline_only_unprofiled.err
-echo "tuner table: $(wc -c < $SR_AUTOTUNE_CACHE) bytes"
 rocprofv3 --kernel-trace --stats -d $OUT/roofline -o out --output-format csv -- python3 $R/bench.py --roofline-only > $OUT/roofline_only.json 2> $OUT/roofline_only.err
 rocprofv3 --kernel-trace --stats -d $OUT/bench -o out --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o out --output-format csv -- python3 $R/bench.py --roofline-only > /dev/null 2>&1
