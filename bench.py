@@ -328,7 +328,7 @@ def main():
         if a.dtype == "f16" and a.views == 8 and shard is None and not a.controlnets and not sdxl:
             traffic, traffic_file = recorded_igemm_traffic(L.lib().sr_source_hash().decode())
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "igemm family: igemm_kernel tiles + conv3p_kernel (implicit-GEMM conv/linear, all %d launches of one UNet eval, B=%d)" % (sub.n, (a.views // world if shard is not None else a.views) * 2),
+        roof = {"bound": "mfma", "kernel": "igemm family: igemm_kernel / igemm_group_kernel tiles + conv3p_kernel (implicit-GEMM conv/linear, all %d ops of one UNet eval, B=%d)" % (sub.n, (a.views // world if shard is not None else a.views) * 2),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 # HBM-side bytes of these launches per UNet evaluation from the FETCH_SIZE (x2, gfx950) + WRITE_SIZE PMC passes of
                 # this very replay: recorded_igemm_traffic() -- null unless the record matches the loaded kernels

@@ -11,7 +11,7 @@ import os
 import sys
 
 out = sys.argv[1]
-FAMILY = ("igemm_kernel", "conv3p_kernel", "splitk_reduce_kernel")
+FAMILY = ("igemm_kernel", "igemm_group_kernel", "conv3p_kernel", "splitk_reduce_kernel")
 
 
 def total(kind):
@@ -31,7 +31,7 @@ res = {"fetch_size_kb_sum": fetch_kb, "write_size_kb_sum": write_kb, "dispatches
        "evaluations_in_pass": evals,
        "fetch_bytes_per_eval_corrected": None if not evals else 2.0 * fetch_kb * 1024 / evals,
        "write_bytes_per_eval": None if not evals else write_kb * 1024 / evals,
-       "note": "FETCH_SIZE x2 (gfx950 counts 16-B-per-lane reads at half); igemm family = igemm_kernel tiles + conv3p_kernel + splitk_reduce_kernel"}
+       "note": "FETCH_SIZE x2 (gfx950 counts 16-B-per-lane reads at half); igemm family = igemm_kernel / igemm_group_kernel tiles + conv3p_kernel + splitk_reduce_kernel"}
 if evals:
     res["hbm_bytes_per_eval"] = res["fetch_bytes_per_eval_corrected"] + res["write_bytes_per_eval"]
 # identity of the kernels that were counted: bench.py quotes the figure only while the loaded library has this source hash
