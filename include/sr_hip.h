@@ -110,6 +110,12 @@ typedef struct {
   int32_t group;          /* plans only (sr_plan_run / sr_plan_capture; sr_igemm ignores it): this op and the next group-1 ops are igemm
                              ops that do not depend on each other (the Q, K and V^T projections of a transformer block; a ResBlock's
                              skip convolution and its first 3x3 convolution) and are handed to sr_igemm_group together.  0 / 1 = alone */
+  int32_t ln_inline;      /* 1: the folded LayerNorm of `row_stats`, with the statistics taken INSIDE this launch: a K-short linear layer
+                             stages every complete input row (K = C1 = the normalised width) through its workgroup anyway, so the waves
+                             sum x and x^2 of the fragments they feed to the MFMAs (v_dot2_f32_f16, fp32 accumulation) and the epilogue
+                             applies out = rstd * (x . W'^T) - rstd * mean * colsum + bias' -- no LayerNorm pass, no statistics pass, no
+                             statistics tensor.  Needs colsum, row_stats == NULL, KH 1, stride 1, one source; never split over K        */
+  float ln_eps;           /* epsilon of that LayerNorm (1e-5 in BasicTransformerBlock)                                                  */
   int32_t reserved_;
 } sr_igemm_args;
 #define SR_IGEMM_SPLIT_COUNTERS 4096

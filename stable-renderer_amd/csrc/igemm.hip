@@ -29,6 +29,15 @@
 
 namespace {
 
+// Folded LayerNorm (sr_igemm_args.row_stats / .ln_inline): the (rstd, -rstd * mean) pair of input row m.  With ln_inline the
+// kernel has left the pairs of its BM rows at the front of the dynamic LDS (the prefetch landing zone, dead by then).
+#define SR_FOLD(p) ((p).row_stats != nullptr || (p).ln_inline != 0)
+__device__ __forceinline__ float2 sr_fold_stat(const sr_igemm_args& p, const int m, const int m0) {
+  extern __shared__ __attribute__((aligned(16))) char sr_lds_front[];
+  if (p.ln_inline) return *(const float2*)(sr_lds_front + 8 * (m - m0));
+  return *(const float2*)(p.row_stats + 2 * (int64_t)m);
+}
+
 // fp16-output form of the row-major epilogue (the coalesced path of epilogue_rows below, same arithmetic and the same stores),
 // restructured after a per-workgroup timeline of the K-short layers (tools/trace_igemm.py) showed the epilogue taking 4.4 us of a
 // 12.5 us workgroup lifetime on the 128x160 tile and 8.4 of 23.5 us on 128x320: on CDNA4 vmcnt counts stores too, so every pass
@@ -78,7 +87,7 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
     const bool vec_lane = tid < BN / 4 && n0 + tid * 4 < N;
     if (vec_lane) {
       if (p.bias) vb = *(const float4*)(p.bias + n0 + tid * 4);
-      if (p.row_stats) vc = *(const float4*)(p.colsum + n0 + tid * 4);
+      if (SR_FOLD(p)) vc = *(const float4*)(p.colsum + n0 + tid * 4);
     }
   }
   uint4 resid[PRE ? NPASS * ITER : 1];
@@ -117,13 +126,13 @@ __device__ __forceinline__ void epilogue_rows_h(const sr_igemm_args& p, f32x4 (&
       const int m = m0 + pm0 + tm * 16 + c16;
       const int b = (p.rowvec && m < M) ? m / rpb : 0;
       float2 rs = make_float2(1.f, 0.f);                     // folded LayerNorm: (rstd, -rstd*mean) of input row m
-      if (p.row_stats && m < M) rs = *(const float2*)(p.row_stats + 2 * (int64_t)m);
+      if (SR_FOLD(p) && m < M) rs = sr_fold_stat(p, m, m0);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         const int nl = qn0 + tn * 16 + 4 * g4, n = n0 + nl;
         float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
         if (n < N) {                                         // N % 4 == 0 on this path
-          if (p.row_stats) {
+          if (SR_FOLD(p)) {
             const float4 cs = *(const float4*)(lvec + BN + nl);
             v[0] = fmaf(rs.x, v[0], rs.y * cs.x); v[1] = fmaf(rs.x, v[1], rs.y * cs.y);
             v[2] = fmaf(rs.x, v[2], rs.y * cs.z); v[3] = fmaf(rs.x, v[3], rs.y * cs.w);
@@ -219,13 +228,13 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
         const int m = m0 + pm0 + tm * 16 + c16;
         const int b = (m < M) ? m / rpb : 0;
         float2 rs = make_float2(1.f, 0.f);                   // folded LayerNorm: (rstd, -rstd*mean) of input row m
-        if (p.row_stats && m < M) rs = *(const float2*)(p.row_stats + 2 * (int64_t)m);
+        if (SR_FOLD(p) && m < M) rs = sr_fold_stat(p, m, m0);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           const int n = n0 + qn0 + tn * 16 + 4 * g4;
           float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
           if (n < N) {                                       // N % 4 == 0 on this path
-            if (p.row_stats) {
+            if (SR_FOLD(p)) {
               const float4 cs = *(const float4*)(p.colsum + n);
               v[0] = fmaf(rs.x, v[0], rs.y * cs.x); v[1] = fmaf(rs.x, v[1], rs.y * cs.y);
               v[2] = fmaf(rs.x, v[2], rs.y * cs.z); v[3] = fmaf(rs.x, v[3], rs.y * cs.w);
@@ -297,8 +306,8 @@ __device__ __forceinline__ void epilogue_rows(const sr_igemm_args& p, f32x4 (&ac
         if (n >= N) continue;
         float v[4] = {acc[tn][tm][0] * scale, acc[tn][tm][1] * scale, acc[tn][tm][2] * scale, acc[tn][tm][3] * scale};
         const int nv = (N - n) < 4 ? (N - n) : 4;
-        if (p.row_stats) {
-          const float2 rs = *(const float2*)(p.row_stats + 2 * (int64_t)m);
+        if (SR_FOLD(p)) {
+          const float2 rs = sr_fold_stat(p, m, m0);
           for (int r = 0; r < nv; ++r) v[r] = fmaf(rs.x, v[r], rs.y * p.colsum[n + r]);
         }
         if (p.bias) { for (int r = 0; r < nv; ++r) v[r] += p.bias[n + r]; }
@@ -357,7 +366,7 @@ __device__ __forceinline__ void wait_leaving(int y) {
 // K-steps of loads in flight instead of one: that tile is otherwise bound by the exposed load latency of every K-step).
 // The kernel body: `bid` of `nblk` is the workgroup's index among the workgroups of THIS problem (blockIdx.x / gridDim.x for an
 // ordinary launch; a grouped launch runs several problems side by side, see igemm_group_kernel)
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1, bool LNI = false>
 __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, const int Ho, const int Wo,
                                            const int NT, const int nwg, const int tile0, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
@@ -404,7 +413,7 @@ __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, 
     if (wv * 64 < CH) {
       const bool second = c >= BN / 4;
       const int n = n0 + 4 * (second ? c - BN / 4 : c);
-      const float* base = second ? (p.row_stats ? p.colsum : nullptr) : p.bias;
+      const float* base = second ? (SR_FOLD(p) ? p.colsum : nullptr) : p.bias;
       const char* src = (base && n < p.N) ? (const char*)(base + n) : (const char*)p.zero_page;
       if (c < CH) sr_glds16_asm(src, __builtin_amdgcn_readfirstlane(sr_lds_addr(smem_raw) + wv * 1024));
     }
@@ -524,6 +533,37 @@ __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, 
 #pragma unroll
     for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- in-launch LayerNorm statistics (sr_igemm_args.ln_inline, kernels instantiated with LNI): K = C1 is the whole normalised row
+  // and every K-step of it passes through this workgroup, so x and x^2 are summed on the way (fp32 accumulators, v_dot2_f32_f16).
+  // The WAVES_N waves that share a row block split its TM fragments (wave wn takes tm = wn, wn + WAVES_N, ...): each reads ITS
+  // fragments once more from LDS at a wave-uniform offset -- a compile-time register index would need a branch per fragment, and
+  // branches in this loop cost the 128- and 256-VGPR tiles their last registers -- i.e. TM / WAVES_N extra ds_read_b128 and 8 VALU
+  // instructions per fragment and k-substep beside 10..40 MFMAs.
+  constexpr int TMS = LNI ? TM / WAVES_N : 1;
+  static_assert(!LNI || (TM % WAVES_N == 0 && !SPLIT), "in-launch LayerNorm statistics: fragments split evenly over the waves of a row block");
+  float lsum[TMS], lsq[TMS];
+#pragma unroll
+  for (int i = 0; i < TMS; ++i) { lsum[i] = 0.f; lsq[i] = 0.f; }
+  auto ln_acc = [&](const char* tP, const int fo) {          // tP: this wave's row block of the X stage
+#pragma unroll
+    for (int i = 0; i < TMS; ++i) {
+      const uint4 x = *(const uint4*)(tP + (wn + i * WAVES_N) * FBLK + fo);
+      if constexpr (sizeof(T) == 2) {
+        const h16x2 one = {(_Float16)1.0f, (_Float16)1.0f};
+        const h16x2 h0 = __builtin_bit_cast(h16x2, x.x), h1 = __builtin_bit_cast(h16x2, x.y);
+        const h16x2 h2 = __builtin_bit_cast(h16x2, x.z), h3 = __builtin_bit_cast(h16x2, x.w);
+        lsum[i] = __builtin_amdgcn_fdot2(h0, one, lsum[i], false); lsq[i] = __builtin_amdgcn_fdot2(h0, h0, lsq[i], false);
+        lsum[i] = __builtin_amdgcn_fdot2(h1, one, lsum[i], false); lsq[i] = __builtin_amdgcn_fdot2(h1, h1, lsq[i], false);
+        lsum[i] = __builtin_amdgcn_fdot2(h2, one, lsum[i], false); lsq[i] = __builtin_amdgcn_fdot2(h2, h2, lsq[i], false);
+        lsum[i] = __builtin_amdgcn_fdot2(h3, one, lsum[i], false); lsq[i] = __builtin_amdgcn_fdot2(h3, h3, lsq[i], false);
+      } else {
+        const float f0 = __uint_as_float(x.x), f1 = __uint_as_float(x.y), f2 = __uint_as_float(x.z), f3 = __uint_as_float(x.w);
+        lsum[i] += f0; lsum[i] += f1; lsum[i] += f2; lsum[i] += f3;
+        lsq[i] = fmaf(f0, f0, lsq[i]); lsq[i] = fmaf(f1, f1, lsq[i]); lsq[i] = fmaf(f2, f2, lsq[i]); lsq[i] = fmaf(f3, f3, lsq[i]);
+      }
+    }
+  };
+
   auto compute = [&](int buf, int j0 = 0, int j1 = BKB / 64) {
     const char* tP = smem + buf * STAGE_BYTES + pm0 * BKB;
     const char* tQ = smem + buf * STAGE_BYTES + BM * BKB + qn0 * BKB;
@@ -534,6 +574,7 @@ __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, 
       for (int t = 0; t < TM; ++t) xf[t] = *(const uint4*)(tP + t * FBLK + foff[j]);
 #pragma unroll
       for (int t = 0; t < TN; ++t) wf[t] = *(const uint4*)(tQ + t * FBLK + foff[j]);
+      if constexpr (LNI) ln_acc(tP, foff[j]);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -573,6 +614,7 @@ __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, 
       for (int t = 0; t < TM; ++t) xf[t] = *(const uint4*)(tP + t * FBLK + foff[j]);
 #pragma unroll
       for (int t = 0; t < TN; ++t) wf[t] = *(const uint4*)(tQ + t * FBLK + foff[j]);
+      if constexpr (LNI) ln_acc(tP, foff[j]);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
@@ -632,6 +674,24 @@ __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, 
   }
 
   SR_TS(3);
+  if constexpr (LNI) {
+    // a lane holds the sums of its 8 (4) k-slots per K-step: add the four k-slot lane groups, finish (rstd, -rstd * mean) and leave
+    // the pair of row pm0 + tm * 16 + c16 at the front of the LDS for the epilogue (sr_fold_stat)
+    const float invk = 1.0f / (float)p.C1;
+#pragma unroll
+    for (int i = 0; i < TMS; ++i) {
+      float su = lsum[i], sq = lsq[i];
+      su += __shfl_xor(su, 16); sq += __shfl_xor(sq, 16);
+      su += __shfl_xor(su, 32); sq += __shfl_xor(sq, 32);
+      const int tm = wn + i * WAVES_N;
+      if (g4 == 0) {
+        const float mean = su * invk, var = fmaxf(fmaf(-mean, mean, sq * invk), 0.f);
+        const float rstd = rsqrtf(var + p.ln_eps);
+        *(float2*)(smem_all + 8 * (pm0 + tm * 16 + c16)) = make_float2(rstd, -rstd * mean);
+      }
+    }
+    __syncthreads();
+  }
   // ---- epilogue
   const float scale = p.scale;
   const int N = p.N;
@@ -697,10 +757,10 @@ __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, 
         if (n >= N) continue;
         const float bz = p.bias ? p.bias[n] : 0.f;
         float v[4] = {acc[tm][tn][0] * scale, acc[tm][tn][1] * scale, acc[tm][tn][2] * scale, acc[tm][tn][3] * scale};
-        if (p.row_stats) {                                 // a lane holds 4 consecutive input rows of one output channel
+        if (SR_FOLD(p)) {                                  // a lane holds 4 consecutive input rows of one output channel
           const float cs = p.colsum[n];
           for (int r = 0; r < 4; ++r)
-            if (m + r < M) { const float2 rs = *(const float2*)(p.row_stats + 2 * (int64_t)(m + r)); v[r] = fmaf(rs.x, v[r], rs.y * cs); }
+            if (m + r < M) { const float2 rs = sr_fold_stat(p, m + r, m0); v[r] = fmaf(rs.x, v[r], rs.y * cs); }
         }
         for (int r = 0; r < 4; ++r) v[r] += bz;
         if (vec) {
@@ -722,10 +782,10 @@ __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, 
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, bool SPLIT = false, int BKB = 128, int SPREAD = 0, int MINB = 1, bool LNI = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_kernel(const sr_igemm_args p, const int M, const int Ho, const int Wo,
                                                                         const int NT, const int nwg, const int tile0) {
-  igemm_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, SPLIT, BKB, SPREAD, MINB>(p, M, Ho, Wo, NT, nwg, tile0, blockIdx.x, gridDim.x);
+  igemm_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, SPLIT, BKB, SPREAD, MINB, LNI>(p, M, Ho, Wo, NT, nwg, tile0, blockIdx.x, gridDim.x);
 }
 
 // Several INDEPENDENT problems in one launch (sr_igemm_group): the workgroups of problem i are the blocks [start[i], start[i+1]).
@@ -740,17 +800,19 @@ struct igemm_group_k {
   int start[SR_IGEMM_GROUP_MAX + 1];
   int n;
 };
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKB = 128, int SPREAD = 0, int MINB = 1>
+// (LNI: the variant that takes LayerNorm statistics inside the launch for the members that ask for them -- sr_igemm_args.ln_inline;
+//  the statistics are summed for every member, applied where the member's flag is set)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKB = 128, int SPREAD = 0, int MINB = 1, bool LNI = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINB) void igemm_group_kernel(const igemm_group_k g) {
   int i = 0;
 #pragma unroll
   for (int j = 1; j < SR_IGEMM_GROUP_MAX; ++j) if (j < g.n && (int)blockIdx.x >= g.start[j]) i = j;
-  igemm_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, false, false, BKB, SPREAD, MINB>(g.p[i], g.M[i], g.Ho[i], g.Wo[i], g.NT[i], g.nwg[i], 0,
-                                                                                     (int)blockIdx.x - g.start[i], g.nwg[i]);
+  igemm_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, false, false, BKB, SPREAD, MINB, LNI>(g.p[i], g.M[i], g.Ho[i], g.Wo[i], g.NT[i], g.nwg[i], 0,
+                                                                                          (int)blockIdx.x - g.start[i], g.nwg[i]);
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKB = 128, int SPREAD = 0, int MINB = 1>
-int launch_group(const sr_igemm_args* const* as, const int* Ms, const int* Hos, const int* Wos, int n, hipStream_t st) {
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKB = 128, int SPREAD = 0, int MINB = 1, bool LNI = false>
+int launch_group_impl(const sr_igemm_args* const* as, const int* Ms, const int* Hos, const int* Wos, int n, hipStream_t st) {
   igemm_group_k g;
   g.n = n;
   int tot = 0;
@@ -769,16 +831,23 @@ int launch_group(const sr_igemm_args* const* as, const int* Ms, const int* Hos, 
   constexpr int lds_epi_all = WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 4 + 16);
   constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
   constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0) + WAVES_M * WAVES_N * 256;
-  auto k = igemm_group_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, BKB, SPREAD, MINB>;
+  auto k = igemm_group_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, BKB, SPREAD, MINB, LNI>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   hipLaunchKernelGGL(k, dim3(tot), dim3(WAVES_M * WAVES_N * 64), lds, st, g);
   SR_CHECK_LAUNCH("sr_igemm_group");
   return SR_OK;
 }
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int BKB = 128, int SPREAD = 0, int MINB = 1>
+int launch_group(const sr_igemm_args* const* as, const int* Ms, const int* Hos, const int* Wos, int n, hipStream_t st) {
+  bool lni = false;
+  for (int i = 0; i < n; ++i) lni = lni || as[i]->ln_inline;
+  if (lni) return launch_group_impl<T, BM, BN, WAVES_M, WAVES_N, STAGES, BKB, SPREAD, MINB, true>(as, Ms, Hos, Wos, n, st);
+  return launch_group_impl<T, BM, BN, WAVES_M, WAVES_N, STAGES, BKB, SPREAD, MINB, false>(as, Ms, Hos, Wos, n, st);
+}
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, int SPREAD = 0, int MINB = 1>
-int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB, int SPREAD, int MINB, bool LNI>
+int launch_impl(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   const int Npad = (a.N + 127) / 128 * 128;
   const int MT = (M + BM - 1) / BM, NT = Npad / BN;
   // skip all-padding n-tiles
@@ -789,13 +858,25 @@ int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   constexpr int lds_epi = lds_epi_all <= lds_stage ? lds_epi_all : WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16);
   constexpr int lds = (lds_stage > lds_epi ? lds_stage : lds_epi) + (sizeof(T) == 2 ? 2 * BN * 4 : 0)    // + the bias / colsum rows (fp16 kernels)
                       + WAVES_M * WAVES_N * 256;                                                           // + the prefetch landing zone
-  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB, SPREAD, MINB>;
+  auto k = igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, false, BKB, SPREAD, MINB, LNI>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   (void)NT;
   hipLaunchKernelGGL(k, dim3(nwg), dim3(WAVES_M * WAVES_N * 64), lds, st, a, M, Ho, Wo, NTv, nwg, 0);
   SR_CHECK_LAUNCH("sr_igemm");
   return SR_OK;
+}
+// tiles without a variant that takes the LayerNorm statistics in the launch (sr_igemm_args.ln_inline): the tuner skips them
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, int SPREAD = 0, int MINB = 1>
+int launch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
+  if (a.ln_inline) SR_FAIL(SR_ERR_INVALID, "sr_igemm: ln_inline is not built for this tile (%d x %d, %d stages)", BM, BN, STAGES);
+  return launch_impl<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, BKB, SPREAD, MINB, false>(a, M, Ho, Wo, st);
+}
+// ... and the tiles that have one: 2, 3, 4, 13 (fp16 / fp32, row-major and transposed), 5, 7, 9, 10, 11, 12 (fp16)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool TRANS, int BKB = 128, int SPREAD = 0, int MINB = 1>
+int launch_ln(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
+  if (a.ln_inline) return launch_impl<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, BKB, SPREAD, MINB, true>(a, M, Ho, Wo, st);
+  return launch_impl<T, BM, BN, WAVES_M, WAVES_N, STAGES, TRANS, BKB, SPREAD, MINB, false>(a, M, Ho, Wo, st);
 }
 
 // (A persistent "K-step stream" form of the 256x320 tile -- one workgroup per CU walking its tiles through the two LDS
@@ -1040,7 +1121,7 @@ __global__ __launch_bounds__(512, 1) void conv3p_kernel(const sr_igemm_args p, c
 }
 
 static bool conv3p_ok(const sr_igemm_args& a, int M) {
-  if (a.dtype != SR_F16 || a.KH != 3 || a.stride != 1 || a.upsample || a.C2 || a.transpose_out || a.row_stats || a.pad_br) return false;
+  if (a.dtype != SR_F16 || a.KH != 3 || a.stride != 1 || a.upsample || a.C2 || a.transpose_out || a.row_stats || a.ln_inline || a.pad_br) return false;
   if (a.C1 % 64 || a.N % 320 || M % 256 || a.act == 2) return false;
   const int rpb = a.H * a.W;
   if (a.W < 8 || 256 % a.W) { if (!(rpb < 256 && 256 % rpb == 0)) return false; }
@@ -1094,7 +1175,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   static const bool split_off = getenv("SR_SPLITK") && atoi(getenv("SR_SPLITK")) == 0;      // tuning / A-B aid
   const int KT = a.KH * a.KH * ((a.C1 + a.C2) / (int)(128 / sizeof(T)));
   const int forceS = a.split > 1 ? a.split : 0;
-  const bool can_split = !TRANS && !split_off && a.split >= 0 && a.workspace && a.act != 2 && a.N % 4 == 0;
+  const bool can_split = !TRANS && !split_off && a.split >= 0 && a.workspace && a.act != 2 && a.N % 4 == 0 && !a.ln_inline;
   const bool may_split = can_split && KT >= 32;
   // Deep-ring tiles for grids of less than one workgroup per CU (13 = 64x64 x 8 stages, 14 = 128x64 x 6, 15 = 128x128 x 4; 128-144
   // KB of LDS, one workgroup per CU).  The 2-stage tiles above have ONE K-step of loads in flight per workgroup and rely on two
@@ -1129,12 +1210,12 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
       if (forceS) SR_FAIL(SR_ERR_INVALID, "sr_igemm: split = %d: nothing to split (whole rounds of workgroups only)", a.split);
     }
   }
-  if (force == 2) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
-  if (force == 3) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
-  if (force == 4) return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
-  if (force == 13) return launch<T, 64, 64, 2, 2, 8, TRANS>(a, M, Ho, Wo, st);
-  if (force == 14) return launch<T, 128, 64, 2, 2, 6, TRANS>(a, M, Ho, Wo, st);
-  if (force == 15) return launch<T, 128, 128, 2, 2, 4, TRANS>(a, M, Ho, Wo, st);
+  if (force == 2) return launch_ln<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if (force == 3) return launch_ln<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if (force == 4) return launch_ln<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if (force == 13) return launch_ln<T, 64, 64, 2, 2, 8, TRANS>(a, M, Ho, Wo, st);
+  if (force == 14) return launch_ln<T, 128, 64, 2, 2, 6, TRANS>(a, M, Ho, Wo, st);
+  if (force == 15) return launch_ln<T, 128, 128, 2, 2, 4, TRANS>(a, M, Ho, Wo, st);
   if (force == 8) {
     if constexpr (!TRANS && sizeof(T) == 2) { if (conv3p_ok(a, M)) return launch_conv3p(a, M, st); }
     SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 8 (patch-stationary 3x3) needs fp16, KH=3, stride 1, one source, N %% 320 == 0, "
@@ -1158,11 +1239,11 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // on the 32x32 GEGLU.  (A 3-slot ring of 64-byte K-steps under the 128x160 tile measured 5..10 % behind the 2 x 128-byte form.)
     if (force == 9) {
       if (a.N % 160) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 9 (128x160) needs N %% 160 == 0, N=%d", a.N);
-      return launch<T, 128, 160, 4, 2, 2, TRANS, 128, 0, 4>(a, M, Ho, Wo, st);
+      return launch_ln<T, 128, 160, 4, 2, 2, TRANS, 128, 0, 4>(a, M, Ho, Wo, st);
     }
     if (force == 10) {
       if (a.N % 320) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile 10 (128x320) needs N %% 320 == 0, N=%d", a.N);
-      return launch<T, 128, 320, 2, 4, 2, TRANS, 64, 0, 4>(a, M, Ho, Wo, st);
+      return launch_ln<T, 128, 320, 2, 4, 2, TRANS, 64, 0, 4>(a, M, Ho, Wo, st);
     }
     // the same idea for layer widths that are multiples of 128 but not of 160 (the VAE decoder): 11 = 128x128 as 8 waves of
     // 32x64 (64 KB), 12 = 256x128 with 64-byte K-steps (49 KB).  844 vs 899 us on the 512x512 C128 conv, 369 vs 457 us on the
@@ -1170,14 +1251,14 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     // (3- and 4-deep rings under the 128x160 tile change nothing on the K-long few-tile layers -- 24.4 us at M4096 K1280 N1280
     //  either way: with 128x160 tiles that layer moves 191 MB from L2 to the CUs, i.e. it runs at the L2 read bandwidth -- and
     //  lose 25 % where two workgroups per CU mattered)
-    if (force == 11) return launch<T, 128, 128, 4, 2, 2, TRANS, 128, 0, 4>(a, M, Ho, Wo, st);
-    if (force == 12) return launch<T, 256, 128, 4, 2, 2, TRANS, 64, 0, 4>(a, M, Ho, Wo, st);
+    if (force == 11) return launch_ln<T, 128, 128, 4, 2, 2, TRANS, 128, 0, 4>(a, M, Ho, Wo, st);
+    if (force == 12) return launch_ln<T, 256, 128, 4, 2, 2, TRANS, 64, 0, 4>(a, M, Ho, Wo, st);
     // 128x320 (8 waves as 2x4, 64x80 per wave, 112 KB): the same full-width rows for layers with half as many pixels -- the
     // 32x32 level (M = 16384, N = 640) gets exactly one round of 256 workgroups: 130 vs 161 us on its 3x3 conv (926 TF/s),
     // 61 vs 80 us on the K = 2560 linear.  (A 64x320 tile for the 16x16 level measured no better than split-K 128x128.)
     if (force == 7 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) < 256 &&
                        (int64_t)((M + 127) / 128) * (a.N / 320) >= 256))
-      return launch<T, 128, 320, 2, 4, 2, TRANS>(a, M, Ho, Wo, st);
+      return launch_ln<T, 128, 320, 2, 4, 2, TRANS>(a, M, Ho, Wo, st);
     // (a 256x160 tile with FOUR waves of 128x80 and 64-byte K-steps -- 53 KB, two workgroups per CU so that one's epilogue
     //  overlaps the other's main loop -- measured 636 vs 1100 TF/s on the big conv and 431 vs 273 us on the 64x64 GEGLU layer)
 
@@ -1185,7 +1266,7 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
     //  +3..9 %, 134 -> 125 us on the 64x64 C320 conv, 1200 -> 1286 TF/s on the big one, 252 -> 236 us on the 64x64 GEGLU;
     //  the 128x320 tile is indifferent to it and the 4-wave tiles lose 5..10 %)
     if (force == 5 || (force == 0 && a.N % 320 == 0 && (int64_t)((M + 255) / 256) * (a.N / 320) >= 256))
-      return launch<T, 256, 320, 4, 2, 2, TRANS, 128, 2>(a, M, Ho, Wo, st);
+      return launch_ln<T, 256, 320, 4, 2, 2, TRANS, 128, 2>(a, M, Ho, Wo, st);
   } else {
     if (force >= 5 && force <= 12) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile %d is fp16, non-transposed only", force);
   }
@@ -1211,16 +1292,16 @@ int dispatch(const sr_igemm_args& a, int M, int Ho, int Wo, hipStream_t st) {
   // (its LDS-DMA is issued piecewise between the MFMA groups -- compute_staging -- which is worth +5..8 % on this 8-wave
   //  tile: 193 -> 176 us on the 64x64 C320 conv, 965 -> 1020 TF/s on the big one; the 4-wave tiles lose 10..20 % with it and
   //  the 256x320 tile has no registers left for it)
-  if (force == 1 || (force == 0 && big))
+  if (force == 1 || (force == 0 && big && !a.ln_inline))
     return launch<T, 256, 128, 4, 2, 3, TRANS, 128, 1>(a, M, Ho, Wo, st);
   // (a 128x160 tile for N = 320 measured slower than five 64-wide tiles on MI355X: 487 vs 612 TF/s on the 3x3 conv)
   // (1x1 layers with few 128x128 tiles run faster on 128x64: three co-resident workgroups per CU hide the short K loop's
   //  ramp; 26.8 vs 31.3 us at M4096 K1280 N1280, 30.8 vs 36.0 at M16384 K640 N640 -- what the per-shape tuner picks too)
-  if (!waste128 && wg_128x128 >= 192 && !(a.KH == 1 && wg_128x128 <= 768)) return launch<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if (!waste128 && wg_128x128 >= 192 && !(a.KH == 1 && wg_128x128 <= 768)) return launch_ln<T, 128, 128, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
   const int64_t wg_128x64 = (int64_t)((M + 127) / 128) * n64;
-  if (wg_128x64 >= 192) return launch<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
-  if ((int64_t)((M + 63) / 64) * n64 <= 256 && KT >= 4) return launch<T, 64, 64, 2, 2, 8, TRANS>(a, M, Ho, Wo, st);   // no co-resident partner: deep ring
-  return launch<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if (wg_128x64 >= 192) return launch_ln<T, 128, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
+  if ((int64_t)((M + 63) / 64) * n64 <= 256 && KT >= 4) return launch_ln<T, 64, 64, 2, 2, 8, TRANS>(a, M, Ho, Wo, st);   // no co-resident partner: deep ring
+  return launch_ln<T, 64, 64, 2, 2, 2, TRANS>(a, M, Ho, Wo, st);
 }
 
 }  // namespace
@@ -1239,7 +1320,8 @@ static int igemm_check(const sr_igemm_args* a, int* M_, int* Ho_, int* Wo_) {
   if (a->N <= 0 || a->B <= 0 || a->H <= 0 || a->W <= 0) SR_FAIL(SR_ERR_INVALID, "sr_igemm: bad sizes");
   if (a->act == 2 && (a->N % 4 || a->transpose_out)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: GEGLU needs N%%4==0");
   if (a->row_stats && !a->colsum) SR_FAIL(SR_ERR_INVALID, "sr_igemm: row_stats without colsum");
-  if (a->row_stats && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
+  if (a->ln_inline && (a->row_stats || !a->colsum)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: ln_inline takes colsum and no row_stats");
+  if ((a->row_stats || a->ln_inline) && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
   if (a->tile < 0 || a->tile > 15 || a->split < -1 || a->split == 1 || a->split > 16) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
   int Ho, Wo;
   if (a->upsample && ((a->up_h > 0) != (a->up_w > 0))) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w go together");

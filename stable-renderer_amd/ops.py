@@ -101,7 +101,7 @@ def split_counters(device):
 
 def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C2=0, bias=None, rowvec=None,
                residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0, tile=0, split=0, row_stats=None, colsum=None,
-               pad_br=0, up_hw=None):
+               pad_br=0, up_hw=None, ln_inline=False, ln_eps=1e-5):
     ar = L.IgemmArgs()
     ar.a, ar.a2, ar.w, ar.bias, ar.rowvec, ar.residual, ar.out = _p(a), _p(a2), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
     ar.zero_page = _p(zero_page(a.device))
@@ -113,6 +113,7 @@ def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C
     ar.tile, ar.split, ar.pad_br = tile, split, pad_br
     ar.up_h, ar.up_w = (0, 0) if (up_hw is None or tuple(up_hw) == (2 * H, 2 * W)) else (int(up_hw[0]), int(up_hw[1]))
     ar.row_stats, ar.colsum = _p(row_stats), _p(colsum)
+    ar.ln_inline, ar.ln_eps = int(bool(ln_inline)), ln_eps
     ws = workspace(a.device)
     ar.workspace, ar.workspace_bytes = _p(ws), ws.numel()
     # The in-GEMM fix-up of split-K (last workgroup of a tile reduces it: sr_igemm_args.split_counters) is parity-clean and
@@ -290,7 +291,7 @@ GROUP_MAX = 4
 
 def _sig(ar, allow_split=True):
     return (ar.dtype, ar.B, ar.H, ar.W, ar.C1, ar.C2, ar.N, ar.KH, ar.stride, ar.upsample, ar.act, ar.transpose_out, ar.out_f32,
-            bool(ar.residual), bool(ar.rowvec), bool(allow_split), bool(ar.row_stats), ar.pad_br, ar.up_h, ar.up_w)
+            bool(ar.residual), bool(ar.rowvec), bool(allow_split), bool(ar.row_stats) + 2 * ar.ln_inline, ar.pad_br, ar.up_h, ar.up_w)
 
 
 def igemm_group(ars, stream=None):

@@ -113,6 +113,12 @@ class BlockLowering:
         # 0.1 ms of extra gathers and +0.3 ms of GEMM epilogue), so the explicit kernels stay the default; SR_FOLD_LN=1 enables
         # it (not in the view-sharded mode)
         self.fold_ln = os.environ.get("SR_FOLD_LN", "0") == "1" and not external
+        # ... or folded with the statistics taken INSIDE the consumer GEMMs (sr_igemm_args.ln_inline): no LayerNorm pass, no
+        # statistics pass, no statistics tensor to gather or broadcast -- also in the view-sharded mode.  SR_LN_INLINE=0 disables
+        self.ln_inline = os.environ.get("SR_LN_INLINE", "1") == "1"
+        # (only where a layer has >= 4096 rows: below that the consumers want split-K / deep-ring split tiles, which cannot take the
+        #  statistics of a whole row, and the LayerNorm kernel they replace is 8 us)
+        self.ln_inline_rows = int(os.environ.get("SR_LN_INLINE_ROWS", "0"))
         self.emb_all = None
         if "_emb_all" in W:
             ntot, kin = shapes["_emb_all"]
@@ -172,8 +178,12 @@ class BlockLowering:
         d = Cc // heads
         fold = self.fold_ln and (inject_idx is None or (HW * 8) % 16 == 0)     # (the statistics rows are gathered in 16-byte units)
 
+        INLINE = "inline"
+
         def normed(x, norm):
             """-> (tensor the consumers read, folded-LN kwargs factory).  fold: the raw rows + their (rstd, -rstd*mean)"""
+            if self.ln_inline and B * HW >= self.ln_inline_rows:
+                return x, INLINE
             if not fold:
                 y = pb.buf(B, HW, Cc)
                 pb.layernorm(x, W[f"{p}.{norm}.g"], W[f"{p}.{norm}.beta"], y, B * HW, Cc)
@@ -189,6 +199,8 @@ class BlockLowering:
                 if (f"{p}.{name}.b") in W:
                     kw["bias"] = W[f"{p}.{name}.b"]
                 return W[f"{p}.{name}"], kw
+            if st is INLINE:
+                return W[f"{p}.{name}.f"], dict(bias=W[f"{p}.{name}.f.b"], ln_inline=True, colsum=W[f"{p}.{name}.f.cs"])
             return W[f"{p}.{name}.f"], dict(bias=W[f"{p}.{name}.f.b"], row_stats=st, colsum=W[f"{p}.{name}.f.cs"])
         ln, st1 = normed(hcur, "norm1")
         q = pb.buf(B, HW, Cc)
@@ -210,10 +222,14 @@ class BlockLowering:
             # K/V of the injected frame(s) only (B-fold fewer projection FLOPs); the frame is picked on the device
             # (rows padded to a whole 128-row tile: as the swapped V^T problem's "weights" the tokens are read tile-wise)
             src = pb.buf(_cdiv(nr * HW, 128) * 128, Cc, zero=True)[:nr * HW].view(nr, HW, Cc)
-            src_st = pb.buf(nr, HW, 2, dtype=torch.float32) if st1 is not None else None
+            # ln_inline: `ln` is the raw residual stream (Q takes its statistics inside its GEMM); the ONE injected frame's raw rows
+            # are picked / received into src_raw and normalised into src by a LayerNorm over nr * HW rows instead of B * HW
+            inline1 = st1 is INLINE
+            src_raw = pb.buf(nr, HW, Cc) if inline1 else src
+            src_st = pb.buf(nr, HW, 2, dtype=torch.float32) if torch.is_tensor(st1) else None
             if self.external:
                 self.schedule.append(("run", pb.take()))
-                self.schedule.append(("bcast", [(ln, src)] + ([(st1, src_st)] if st1 is not None else [])))
+                self.schedule.append(("bcast", [(ln, src_raw)] + ([(st1, src_st)] if torch.is_tensor(st1) else [])))
                 wq, kq = lin("attn1.to_q", st1)
                 pb.igemm(ln, wq, q, B * HW, 1, 1, Cc, Cc, **kq)
                 self.schedule.append(("run", pb.take()))
@@ -223,13 +239,15 @@ class BlockLowering:
             # V^T = Wv . src^T is written as the row-major GEMM with the operands' roles swapped -- the packed weight rows
             # [C, K] are the "pixels", the gathered tokens [Tk, K] the "weights", out[c][t] with row stride Tk -- so that all
             # three are row-major problems of one kernel (needs ldt == Tk and no folded LayerNorm; else the transposed-output form)
-            swap_v = ldt == Tk and st1 is None and not pb.two_lanes and (p + ".attn1.to_v.b") not in W
+            swap_v = ldt == Tk and src_st is None and not pb.two_lanes and (p + ".attn1.to_v.b") not in W
             pb.fork()
             with pb.side():
                 if not self.external:
-                    pb.gather_rows(ln, sel, src, nr, HW * Cc * ln.element_size(), B, self.sel_err)
-                    if st1 is not None:
+                    pb.gather_rows(ln, sel, src_raw, nr, HW * Cc * ln.element_size(), B, self.sel_err)
+                    if torch.is_tensor(st1):
                         pb.gather_rows(st1, sel, src_st, nr, HW * 2 * 4, B, self.sel_err)
+                if inline1:
+                    pb.layernorm(src_raw, W[f"{p}.norm1.g"], W[f"{p}.norm1.beta"], src, nr * HW, Cc)
                 wk, kk = lin("attn1.to_k", src_st)
                 wv, kv = lin("attn1.to_v", src_st)
                 calls = [((src, wk, k, Tk, 1, 1, Cc, Cc), kk)]

@@ -378,10 +378,12 @@ def test_igemm_patch_stationary_conv3(ops, shape, act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("inline", [False, True])
 @pytest.mark.parametrize("mode", ["plain", "geglu", "transposed", "residual_big"])
-def test_igemm_folded_layernorm(ops, dtype, mode):
-    """Linear(LayerNorm(x)) with the normalisation folded into the GEMM (sr_row_stats + sr_igemm_args.row_stats/colsum):
-    the GEMM reads the raw rows; rows with a large mean relative to their spread exercise the cancellation"""
+def test_igemm_folded_layernorm(ops, dtype, mode, inline):
+    """Linear(LayerNorm(x)) with the normalisation folded into the GEMM (sr_row_stats + sr_igemm_args.row_stats/colsum, or
+    ln_inline: the statistics taken inside the launch): the GEMM reads the raw rows; rows with a large mean relative to their
+    spread exercise the cancellation"""
     dev = "cuda"
     ke = ops.kelems(dtype)
     M, K, N = (4096 + 13, 320, 640) if mode == "residual_big" else (333, 5 * ke, 256)
@@ -399,6 +401,8 @@ def test_igemm_folded_layernorm(ops, dtype, mode):
     rstd = (var + 1e-5).rsqrt()
     assert torch.allclose(st[:, 0].cpu(), rstd, rtol=2e-4) and torch.allclose(st[:, 1].cpu(), -rstd * mean, rtol=2e-4, atol=1e-4)
     kw = dict(bias=b2.to(dev), row_stats=st, colsum=cs.to(dev))
+    if inline:
+        kw = dict(bias=b2.to(dev), ln_inline=True, ln_eps=1e-5, colsum=cs.to(dev))
     if mode == "transposed":
         ldt = (M + 7) // 8 * 8
         out = torch.zeros(1, N, ldt, dtype=dtype, device=dev)
@@ -420,6 +424,39 @@ def test_igemm_folded_layernorm(ops, dtype, mode):
     torch.cuda.synchronize()
     # the reference rounds LN(x) to `dtype` before the GEMM, the folded form does not: same tolerance class as the GEMM itself
     close(got, ref, dtype, scale=ref.abs().max().item())
+
+
+@pytest.mark.parametrize("tile", [2, 3, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("geglu", [False, True])
+def test_igemm_inline_layernorm_tiles(ops, tile, geglu):
+    """every tile that has a variant taking the LayerNorm statistics inside the launch (ln_inline), at the UNet's three widths
+    (K = 320 / 640 / 1280: 5, 10, 20 K-steps), ragged M, residual or GEGLU; the tiles without one refuse the flag"""
+    dtype, dev = torch.float16, "cuda"
+    for K in (320, 640, 1280):
+        M, N = 1000, 640
+        x = rnd(1, M, K) * 1.3 + rnd(2, M, 1) * 2.0
+        gamma, beta = 1 + 0.2 * rnd(3, K), 0.1 * rnd(4, K)
+        w, bias = rnd(5, N, K) * K ** -0.5, rnd(6, N) * 0.1
+        xd = x.to(dtype)
+        ref = F.layer_norm(xd.float(), (K,), gamma, beta, 1e-5) @ w.to(dtype).float().t() + bias
+        wp, cs, b2 = ops.fold_layernorm(w, bias, gamma, beta, dtype, geglu=geglu)
+        rs = None
+        if geglu:
+            a, g = ref.chunk(2, dim=1)
+            ref = a * F.gelu(g)
+        else:
+            resid = rnd(7, M, N)
+            ref = ref + resid.to(dtype).float()
+            rs = resid.to(dtype).to(dev)
+        out = torch.zeros(M, N // 2 if geglu else N, dtype=dtype, device=dev)
+        ops.igemm(xd.to(dev), wp.to(dev), out, M, 1, 1, K, N, act=2 if geglu else 0, residual=rs, bias=b2.to(dev), colsum=cs.to(dev),
+                  ln_inline=True, tile=tile, split=-1)
+        torch.cuda.synchronize()
+        close(out, ref, dtype, scale=ref.abs().max().item())
+    from stable_renderer_amd import _lib as L
+    for bad in (1, 6):
+        with pytest.raises(L.SrHipError):
+            ops.igemm(xd.to(dev), wp.to(dev), out, M, 1, 1, K, N, act=2 if geglu else 0, bias=b2.to(dev), colsum=cs.to(dev), ln_inline=True, tile=bad, split=-1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -211,6 +211,7 @@ def test_unet_tiny_with_folded_layernorm(monkeypatch):
     gather of raw rows + statistics; same goldens as the explicit-LayerNorm plan"""
     from stable_renderer_amd.unet import SD15_CFG
     monkeypatch.setenv("SR_FOLD_LN", "1")
+    monkeypatch.setenv("SR_LN_INLINE", "0")                    # (the row-statistics form; the in-GEMM form is the default: next test)
     cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
     d = np.load(os.path.join(GOLD, "unet_tiny.npz"))
     sd = _sd("unet_tiny_keys.json", 1)
@@ -219,3 +220,29 @@ def test_unet_tiny_with_folded_layernorm(monkeypatch):
         assert any(p["step"].ops[i].kind == 14 for i in range(p["step"].n)), "row-stats ops expected in the folded plan"
         ref = T(d[key])
         assert (y - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 2e-3), (torch.float16, 6e-2)])
+def test_unet_tiny_layernorm_inside_the_consumer_gemms(dtype, atol, monkeypatch):
+    """the default lowering: norm1 / norm2 / norm3 folded into to_q / attn2.to_q / ff.net.0 with the row statistics taken INSIDE
+    those GEMMs (sr_igemm_args.ln_inline) -- no LayerNorm launch over the B frames (the ONE injected frame's rows are normalised by
+    a LayerNorm over HW rows for its K / V projections), against the same goldens; SR_LN_INLINE=0 brings the launches back"""
+    from stable_renderer_amd import _lib as L
+    from stable_renderer_amd.unet import SD15_CFG
+    cfg = dict(SD15_CFG, model_channels=64, context_dim=64)
+    d = np.load(os.path.join(GOLD, "unet_tiny.npz"))
+    sd = _sd("unet_tiny_keys.json", 1)
+
+    def count(p, kind):
+        return sum(1 for i in range(p["step"].n) if p["step"].ops[i].kind == kind)
+    for key, inject in (("y", None), ("y_inj", [int(v) for v in np.atleast_1d(d["inj_idx"])])):
+        monkeypatch.setenv("SR_LN_INLINE", "0")
+        _, base = run_unet(sd, cfg, dtype, T(d["x"]), T(d["t"]), T(d["ctx"]), inject=inject)
+        monkeypatch.setenv("SR_LN_INLINE", "1")
+        y, p = run_unet(sd, cfg, dtype, T(d["x"]), T(d["t"]), T(d["ctx"]), inject=inject)
+        n_blocks = count(base, L.OP_LAYERNORM) // 3
+        assert count(p, L.OP_LAYERNORM) == (n_blocks if inject is not None else 0)      # one small LayerNorm per injected block
+        n_inline = sum(1 for i in range(p["step"].n) if p["step"].ops[i].kind == L.OP_IGEMM and p["step"].ops[i].u.igemm.ln_inline)
+        assert n_inline == (3 if inject is not None else 5) * n_blocks                  # q, q2, ff1 (+ k, v without injection)
+        ref = T(d[key])
+        assert (y - ref).abs().max().item() < atol * max(1.0, ref.abs().max().item())
