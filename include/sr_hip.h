@@ -149,6 +149,13 @@ int sr_row_stats(const void* x, float* stats, int32_t rows, int32_t C, float eps
 /* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3, attention.py:521,613,648). rows x C. */
 int sr_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t rows, int32_t C,
                  float eps, int32_t dtype, void* stream);
+/* The same over GATHERED rows: output row r = LayerNorm of row sel[r / frame_rows] * frame_rows + r % frame_rows of x ([n_frames,
+ * frame_rows, C]); sel is a DEVICE array of nsel frame indices.  With sr_igemm_args.ln_inline the B-frame LayerNorm in front of the
+ * self-attention disappears into the Q projection and only the K/V-injected frame's tokens need normalising
+ * (OverlapCorresponder.pre_atten_inject, corresponder.py:204-214): this is that LayerNorm and the pick of the frame in one launch.
+ * An index outside [0, n_frames) gives zero rows and raises *err_flag (as sr_gather_rows). */
+int sr_layernorm_gather(const void* x, const int32_t* sel, int32_t nsel, int32_t frame_rows, int32_t n_frames, int32_t* err_flag,
+                        const float* gamma, const float* beta, void* y, int32_t C, float eps, int32_t dtype, void* stream);
 
 /* Fused softmax(Q K^T / sqrt(d)) V (optimized_attention, attention.py:92-387), fp32 softmax statistics.
  *  q  [B, Tq, heads*d]   k [Bk, Tk, heads*d]   vt [Bk, heads, d, ldt] (V transposed, written by sr_igemm
@@ -193,7 +200,8 @@ typedef enum {
   SR_OP_NHWC_TO_NCHW = 6, SR_OP_TIMESTEP_EMBED = 7, SR_OP_SILU = 8, SR_OP_SOFTMAX_ROWS = 9, SR_OP_GATHER_ROWS = 10, SR_OP_ADD_SCALED = 11,
   SR_OP_FORK = 12,   /* side lane may start: it waits for everything issued on the main lane so far                       */
   SR_OP_JOIN = 13,   /* main lane waits for everything issued on the side lane so far                                     */
-  SR_OP_ROW_STATS = 14 /* sr_row_stats; uses the `ln` member: x, y = stats, rows, C, dtype, eps                           */
+  SR_OP_ROW_STATS = 14, /* sr_row_stats; uses the `ln` member: x, y = stats, rows, C, dtype, eps                          */
+  SR_OP_LAYERNORM_GATHER = 15 /* sr_layernorm_gather; the `ln` member with sel / err_flag / frame_rows / n_frames, rows = nsel * frame_rows */
 } sr_op_kind;
 /* lane: 0 = the caller's stream, 1 = the executor's side stream.  Independent branches of the graph (a ResBlock's 1x1
  * skip convolution beside its GroupNorm/conv path; the injected frame's K/V projections beside the Q projection) are
@@ -205,7 +213,8 @@ typedef struct {
     sr_igemm_args igemm;
     sr_groupnorm_args gn;
     sr_attention_args attn;
-    struct { const void* x; const float* gamma; const float* beta; void* y; int32_t rows, C, dtype; float eps; } ln;
+    struct { const void* x; const float* gamma; const float* beta; void* y; int32_t rows, C, dtype; float eps;
+             const int32_t* sel; int32_t* err_flag; int32_t frame_rows, n_frames; } ln;   /* (the last four: SR_OP_LAYERNORM_GATHER) */
     struct { const void* x; void* y; const float* per_batch_scale; int32_t B, C, HW, Cpad, dtype, ldc; float scale; } cvt;
     struct { const float* t; void* y; int32_t B, dim, dtype; } temb;
     struct { const void* x; void* y; int64_t n; int32_t dtype; int32_t rows, cols; } ew;

@@ -9,7 +9,7 @@ _DEV_LIB = os.environ.get("SR_DEV_LIB")          # development only: an experime
 
 SR_F16, SR_F32 = 0, 1
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_TIMESTEP_EMBED, OP_SILU,
- OP_SOFTMAX_ROWS, OP_GATHER_ROWS, OP_ADD_SCALED, OP_FORK, OP_JOIN, OP_ROW_STATS) = range(1, 15)
+ OP_SOFTMAX_ROWS, OP_GATHER_ROWS, OP_ADD_SCALED, OP_FORK, OP_JOIN, OP_ROW_STATS, OP_LAYERNORM_GATHER) = range(1, 16)
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -38,7 +38,8 @@ class AttentionArgs(C.Structure):
 
 
 class _Ln(C.Structure):
-    _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("y", vp), ("rows", i32), ("C", i32), ("dtype", i32), ("eps", f32)]
+    _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("y", vp), ("rows", i32), ("C", i32), ("dtype", i32), ("eps", f32),
+                ("sel", vp), ("err_flag", vp), ("frame_rows", i32), ("n_frames", i32)]
 
 
 class _Cvt(C.Structure):
@@ -101,6 +102,7 @@ SYMBOLS = {
     "sr_model_read": (C.c_int, [vp, C.c_char_p, vp, vp]),
     "sr_unet_forward": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "sr_vae_decode": (C.c_int, [vp, vp, vp, vp]),
+    "sr_layernorm_gather": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, i32, vp]),
     "sr_igemm": (C.c_int, [P(IgemmArgs), vp]),
     "sr_igemm_group": (C.c_int, [P(P(IgemmArgs)), i32, vp]),
     "sr_groupnorm": (C.c_int, [P(GroupNormArgs), vp]),

@@ -21,7 +21,7 @@ from . import _lib as L
 from . import ops as O
 
 _MEMBER = {L.OP_IGEMM: ("igemm", L.IgemmArgs), L.OP_GROUPNORM: ("gn", L.GroupNormArgs), L.OP_ATTENTION: ("attn", L.AttentionArgs),
-           L.OP_LAYERNORM: ("ln", L._Ln), L.OP_ROW_STATS: ("ln", L._Ln), L.OP_NCHW_TO_NHWC: ("cvt", L._Cvt),
+           L.OP_LAYERNORM: ("ln", L._Ln), L.OP_ROW_STATS: ("ln", L._Ln), L.OP_LAYERNORM_GATHER: ("ln", L._Ln), L.OP_NCHW_TO_NHWC: ("cvt", L._Cvt),
            L.OP_NHWC_TO_NCHW: ("cvt", L._Cvt), L.OP_TIMESTEP_EMBED: ("temb", L._Temb), L.OP_SILU: ("ew", L._Ew),
            L.OP_SOFTMAX_ROWS: ("ew", L._Ew), L.OP_GATHER_ROWS: ("gather", L._Gather), L.OP_ADD_SCALED: ("add", L._Add)}
 SMALL = 64 << 10          # tensors up to this size keep their contents (index tensors, flags, norm parameters outside the weight dict)

@@ -49,6 +49,7 @@ static std::vector<size_t> pointer_fields(int kind) {
     case SR_OP_GROUPNORM: return {F(gn, x), F(gn, x2), F(gn, gamma), F(gn, beta), F(gn, y), F(gn, partials)};
     case SR_OP_ATTENTION: return {F(attn, q), F(attn, k), F(attn, vt), F(attn, o)};
     case SR_OP_LAYERNORM: case SR_OP_ROW_STATS: return {F(ln, x), F(ln, gamma), F(ln, beta), F(ln, y)};
+    case SR_OP_LAYERNORM_GATHER: return {F(ln, x), F(ln, gamma), F(ln, beta), F(ln, y), F(ln, sel), F(ln, err_flag)};
     case SR_OP_NCHW_TO_NHWC: case SR_OP_NHWC_TO_NCHW: return {F(cvt, x), F(cvt, y), F(cvt, per_batch_scale)};
     case SR_OP_TIMESTEP_EMBED: return {F(temb, t), F(temb, y)};
     case SR_OP_SILU: case SR_OP_SOFTMAX_ROWS: return {F(ew, x), F(ew, y)};

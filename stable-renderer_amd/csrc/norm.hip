@@ -504,6 +504,22 @@ bool try_gn_wave(const sr_groupnorm_args* a, hipStream_t st) {
   return true;
 }
 
+// optional row gather in front of the LayerNorm (sr_layernorm_gather): output row r is the LayerNorm of row
+// sel[r / frame_rows] * frame_rows + r % frame_rows of x -- the ONE K/V-injected frame of a batch, picked by a device index
+// (OverlapCorresponder.pre_atten_inject, corresponder.py:204-214) and normalised in the same launch.  An index outside the batch
+// gives zero rows and raises *err, as sr_gather_rows does.
+struct ln_gather { const int* sel; int* err; int frame_rows, n_frames; };
+__device__ __forceinline__ int64_t ln_src_row(const ln_gather& g, int row, bool& ok) {
+  if (!g.sel) return row;
+  const int j = row / g.frame_rows, f = g.sel[j];
+  if (f < 0 || f >= g.n_frames) {
+    ok = false;
+    if (g.err) atomicOr(g.err, 1);
+    return 0;
+  }
+  return (int64_t)f * g.frame_rows + (row - j * g.frame_rows);
+}
+
 // one wave per row
 // One wave per ROWS consecutive rows (MAXC 16-byte chunks per lane and row): with one 640-byte row per wave the kernel is a chain
 // load -> two shuffle trees -> store with ~20 KB in flight per CU (3.2 TB/s at rows 65536, C 320); ROWS independent rows per
@@ -511,20 +527,26 @@ bool try_gn_wave(const sr_groupnorm_args* a, hipStream_t st) {
 // centred second moment) is unchanged.
 template <typename T, int MAXC, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        T* __restrict__ y, int rows, int C, float eps) {
+                                                        T* __restrict__ y, int rows, int C, float eps, const ln_gather g) {
   constexpr int EPC = sr_traits<T>::EPC;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS, lane = threadIdx.x & 63;
   if (row0 >= rows) return;
   const int cpt = C / EPC;
   float v[ROWS][MAXC][EPC];
   float s[ROWS], q[ROWS];
+  bool okr[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     s[r] = 0.f;
+    okr[r] = true;
+    const int64_t srow = row0 + r < rows ? ln_src_row(g, row0 + r, okr[r]) : 0;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int cc = lane + i * 64;
-      if (cc < cpt && row0 + r < rows) load_chunk<T>(x + (int64_t)(row0 + r) * C + cc * EPC, v[r][i]);
+      if (cc < cpt && row0 + r < rows) {
+        if (okr[r]) load_chunk<T>(x + srow * C + cc * EPC, v[r][i]);
+        else { for (int e = 0; e < EPC; ++e) v[r][i][e] = 0.f; }
+      }
     }
   }
 #pragma unroll
@@ -567,7 +589,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
       if (cc < cpt && row0 + r < rows) {
         float o[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) o[e] = (v[r][i][e] - mean) * rstd * gamma[cc * EPC + e] + beta[cc * EPC + e];
+        for (int e = 0; e < EPC; ++e) o[e] = okr[r] ? (v[r][i][e] - mean) * rstd * gamma[cc * EPC + e] + beta[cc * EPC + e] : 0.f;
         store_chunk<T>(y + (int64_t)(row0 + r) * C + cc * EPC, o);
       }
     }
@@ -581,15 +603,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // Mean then centred second moment, as above.
 template <typename T, int LPR, int NCH>
 __global__ __launch_bounds__(256) void layernorm_sub_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            T* __restrict__ y, int rows, int C, float eps) {
+                                                            T* __restrict__ y, int rows, int C, float eps, const ln_gather g) {
   constexpr int EPC = sr_traits<T>::EPC, RPW = 64 / LPR;
   using VEC = typename std::conditional<sizeof(T) == 2, h16x8, f32x4>::type;
   const int lane = threadIdx.x & 63, sub = lane & (LPR - 1);
   const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
   const bool on = row < rows;
+  bool ok = true;
+  const int64_t srow = on ? ln_src_row(g, row, ok) : 0;
   VEC raw[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) raw[i] = on ? *(const VEC*)(x + (int64_t)row * C + (sub + i * LPR) * EPC) : VEC{};
+  for (int i = 0; i < NCH; ++i) raw[i] = (on && ok) ? *(const VEC*)(x + srow * C + (sub + i * LPR) * EPC) : VEC{};
   float v[NCH][EPC];
   float s = 0.f;
 #pragma unroll
@@ -615,7 +639,7 @@ __global__ __launch_bounds__(256) void layernorm_sub_kernel(const T* __restrict_
     const int c0 = (sub + i * LPR) * EPC;
     float o[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+    for (int e = 0; e < EPC; ++e) o[e] = ok ? (v[i][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e] : 0.f;
     store_chunk<T>(y + (int64_t)row * C + c0, o);
   }
 }
@@ -721,8 +745,8 @@ extern "C" int sr_groupnorm(const sr_groupnorm_args* a, void* stream) {
   return SR_OK;
 }
 
-extern "C" int sr_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t rows, int32_t C,
-                            float eps, int32_t dtype, void* stream) {
+static int layernorm_impl(const void* x, const float* gamma, const float* beta, void* y, int32_t rows, int32_t C,
+                          float eps, int32_t dtype, void* stream, const ln_gather g) {
   if (!x || !y || !gamma || !beta) SR_FAIL(SR_ERR_INVALID, "sr_layernorm: null pointer");
   const int epc = dtype == SR_F16 ? 8 : 4;
   if (C % epc || C / epc > 64 * 5) SR_FAIL(SR_ERR_INVALID, "sr_layernorm: C=%d unsupported", C);
@@ -731,7 +755,7 @@ extern "C" int sr_layernorm(const void* x, const float* gamma, const float* beta
   auto go = [&](auto t, auto maxc, auto nrows) {
     using T = decltype(t);
     constexpr int MAXC = decltype(maxc)::value, ROWS = decltype(nrows)::value;
-    hipLaunchKernelGGL((layernorm_kernel<T, MAXC, ROWS>), dim3(sr_cdiv(rows, 4 * ROWS)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, eps);
+    hipLaunchKernelGGL((layernorm_kernel<T, MAXC, ROWS>), dim3(sr_cdiv(rows, 4 * ROWS)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, eps, g);
   };
   using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
@@ -745,7 +769,7 @@ extern "C" int sr_layernorm(const void* x, const float* gamma, const float* beta
       const int lpr = cpt / nch;
       if (lpr > 32 || (lpr & (lpr - 1))) continue;
       const dim3 grid(sr_cdiv(rows, 4 * (64 / lpr)));
-#define SR_LN_SUB(L, N) hipLaunchKernelGGL((layernorm_sub_kernel<T, L, N>), grid, dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, eps); return true
+#define SR_LN_SUB(L, N) hipLaunchKernelGGL((layernorm_sub_kernel<T, L, N>), grid, dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, rows, C, eps, g); return true
 #define SR_LN_SUBN(L) switch (nch) { case 1: SR_LN_SUB(L, 1); case 2: SR_LN_SUB(L, 2); case 3: SR_LN_SUB(L, 3); case 4: SR_LN_SUB(L, 4); default: SR_LN_SUB(L, 5); }
       switch (lpr) {
         case 1: SR_LN_SUBN(1)
@@ -774,4 +798,15 @@ extern "C" int sr_layernorm(const void* x, const float* gamma, const float* beta
   else SR_FAIL(SR_ERR_INVALID, "sr_layernorm: dtype");
   SR_CHECK_LAUNCH("sr_layernorm");
   return SR_OK;
+}
+
+extern "C" int sr_layernorm(const void* x, const float* gamma, const float* beta, void* y, int32_t rows, int32_t C,
+                            float eps, int32_t dtype, void* stream) {
+  return layernorm_impl(x, gamma, beta, y, rows, C, eps, dtype, stream, ln_gather{nullptr, nullptr, 1, 0});
+}
+
+extern "C" int sr_layernorm_gather(const void* x, const int32_t* sel, int32_t nsel, int32_t frame_rows, int32_t n_frames, int32_t* err_flag,
+                                   const float* gamma, const float* beta, void* y, int32_t C, float eps, int32_t dtype, void* stream) {
+  if (!sel || nsel < 1 || frame_rows < 1 || n_frames < 1) SR_FAIL(SR_ERR_INVALID, "sr_layernorm_gather: bad selection");
+  return layernorm_impl(x, gamma, beta, y, nsel * frame_rows, C, eps, dtype, stream, ln_gather{sel, err_flag, frame_rows, n_frames});
 }

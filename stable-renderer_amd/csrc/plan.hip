@@ -11,6 +11,10 @@ static int run_op(const sr_op& op, void* stream) {
     case SR_OP_ATTENTION: return sr_attention(&op.u.attn, stream);
     case SR_OP_LAYERNORM:
       return sr_layernorm(op.u.ln.x, op.u.ln.gamma, op.u.ln.beta, op.u.ln.y, op.u.ln.rows, op.u.ln.C, op.u.ln.eps, op.u.ln.dtype, stream);
+    case SR_OP_LAYERNORM_GATHER:
+      if (op.u.ln.frame_rows < 1 || op.u.ln.rows % op.u.ln.frame_rows) { sr_set_error("sr_plan_run: layernorm_gather: rows %% frame_rows"); return SR_ERR_INVALID; }
+      return sr_layernorm_gather(op.u.ln.x, op.u.ln.sel, op.u.ln.rows / op.u.ln.frame_rows, op.u.ln.frame_rows, op.u.ln.n_frames, op.u.ln.err_flag,
+                                 op.u.ln.gamma, op.u.ln.beta, op.u.ln.y, op.u.ln.C, op.u.ln.eps, op.u.ln.dtype, stream);
     case SR_OP_ROW_STATS:
       return sr_row_stats(op.u.ln.x, (float*)op.u.ln.y, op.u.ln.rows, op.u.ln.C, op.u.ln.eps, op.u.ln.dtype, stream);
     case SR_OP_NCHW_TO_NHWC:

@@ -177,6 +177,15 @@ class PlanBuilder:
         a.rows, a.C, a.dtype, a.eps = rows, Cc, O.DT[self.dtype], eps
         self._emit(L.OP_LAYERNORM, "ln", a)
 
+    def layernorm_gather(self, x, sel, nsel, frame_rows, n_frames, gamma, beta, y, Cc, err_flag=None, eps=1e-5):
+        """y[j * frame_rows + r] = LayerNorm(x[sel[j], r]) (sr_layernorm_gather): the injected frame picked and normalised at once"""
+        self.hold(x, sel, gamma, beta, y, err_flag)
+        a = L._Ln()
+        a.x, a.gamma, a.beta, a.y = O._p(x), O._p(gamma), O._p(beta), O._p(y)
+        a.rows, a.C, a.dtype, a.eps = nsel * frame_rows, Cc, O.DT[self.dtype], eps
+        a.sel, a.err_flag, a.frame_rows, a.n_frames = O._p(sel), O._p(err_flag), frame_rows, n_frames
+        self._emit(L.OP_LAYERNORM_GATHER, "ln", a)
+
     def row_stats(self, x, stats, rows, Cc, eps=1e-5):
         self.hold(x, stats)
         a = L._Ln()

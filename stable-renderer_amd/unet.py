@@ -114,10 +114,11 @@ class BlockLowering:
         # it (not in the view-sharded mode)
         self.fold_ln = os.environ.get("SR_FOLD_LN", "0") == "1" and not external
         # ... or folded with the statistics taken INSIDE the consumer GEMMs (sr_igemm_args.ln_inline): no LayerNorm pass, no
-        # statistics pass, no statistics tensor to gather or broadcast -- also in the view-sharded mode.  SR_LN_INLINE=0 disables
+        # statistics pass, no statistics tensor to gather or broadcast -- also in the view-sharded mode.  The default since round 4
+        # (same box, B = 16 evaluation 18.72 -> 18.44 ms, B = 6 9.70 -> 9.52, B = 2 5.92 -> 5.87; 390 -> 358 ops); SR_LN_INLINE=0 disables
         self.ln_inline = os.environ.get("SR_LN_INLINE", "1") == "1"
-        # (only where a layer has >= 4096 rows: below that the consumers want split-K / deep-ring split tiles, which cannot take the
-        #  statistics of a whole row, and the LayerNorm kernel they replace is 8 us)
+        # (SR_LN_INLINE_ROWS = n keeps the LayerNorm kernels where a layer has fewer than n rows: there the consumers lose their
+        #  split-K forms to the statistics, which need the whole row in one workgroup -- measured a wash at B = 2, a gain above)
         self.ln_inline_rows = int(os.environ.get("SR_LN_INLINE_ROWS", "0"))
         self.emb_all = None
         if "_emb_all" in W:
@@ -242,11 +243,13 @@ class BlockLowering:
             swap_v = ldt == Tk and src_st is None and not pb.two_lanes and (p + ".attn1.to_v.b") not in W
             pb.fork()
             with pb.side():
-                if not self.external:
+                if inline1 and not self.external:            # the frame picked and normalised in ONE launch
+                    pb.layernorm_gather(ln, sel, nr, HW, B, W[f"{p}.norm1.g"], W[f"{p}.norm1.beta"], src, Cc, err_flag=self.sel_err)
+                elif not self.external:
                     pb.gather_rows(ln, sel, src_raw, nr, HW * Cc * ln.element_size(), B, self.sel_err)
                     if torch.is_tensor(st1):
                         pb.gather_rows(st1, sel, src_st, nr, HW * 2 * 4, B, self.sel_err)
-                if inline1:
+                if inline1 and self.external:                # the rows another rank sent
                     pb.layernorm(src_raw, W[f"{p}.norm1.g"], W[f"{p}.norm1.beta"], src, nr * HW, Cc)
                 wk, kk = lin("attn1.to_k", src_st)
                 wv, kv = lin("attn1.to_v", src_st)

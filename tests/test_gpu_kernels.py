@@ -766,6 +766,32 @@ def test_sampler_math(ops):
         assert torch.allclose(xg.cpu(), ref, atol=2e-5, rtol=1e-5), sampler
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cc", [320, 640, 1280, 96])
+def test_layernorm_gather_picks_and_normalises_in_one_launch(ops, dtype, Cc):
+    """sr_layernorm_gather = sr_gather_rows + sr_layernorm bit for bit (two injected frames, device indices), and an index outside
+    the batch gives zero rows and raises the device flag"""
+    import ctypes as C
+    from stable_renderer_amd import _lib as L
+    B, HW = 5, 37
+    x = (rnd(1, B, HW, Cc) * 1.4 + rnd(2, B, HW, 1)).to(dtype).cuda()
+    gamma, beta = (1 + 0.1 * rnd(3, Cc)).cuda(), (0.1 * rnd(4, Cc)).cuda()
+    sel = torch.tensor([3, 1], dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    y = torch.empty(2, HW, Cc, dtype=dtype, device="cuda")
+    L.check(L.lib().sr_layernorm_gather(ops._p(x), ops._p(sel), 2, HW, B, ops._p(err), ops._p(gamma), ops._p(beta), ops._p(y), Cc, 1e-5,
+                                        ops.DT[dtype], ops.stream_ptr()))
+    ref = ops.layernorm(x[[3, 1]].contiguous(), gamma, beta)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref) and int(err.item()) == 0
+    close(y, F.layer_norm(x[[3, 1]].float().cpu(), (Cc,), gamma.cpu(), beta.cpu(), 1e-5), dtype, scale=3.0)
+    sel.copy_(torch.tensor([3, 7], dtype=torch.int32))
+    L.check(L.lib().sr_layernorm_gather(ops._p(x), ops._p(sel), 2, HW, B, ops._p(err), ops._p(gamma), ops._p(beta), ops._p(y), Cc, 1e-5,
+                                        ops.DT[dtype], ops.stream_ptr()))
+    torch.cuda.synchronize()
+    assert int(err.item()) == 1 and float(y[1].abs().max()) == 0.0 and torch.equal(y[0], ref[0])
+
+
 def test_gather_rows_rejects_out_of_range_index(ops):
     """sr_gather_rows never dereferences a device index outside [0, n_rows): the row is zero-filled and the sticky device flag is
     raised (round 1 recorded a GPU memory fault from exactly this: a global batch index selecting a row of a rank-local batch)"""

@@ -241,7 +241,9 @@ def test_unet_tiny_layernorm_inside_the_consumer_gemms(dtype, atol, monkeypatch)
         monkeypatch.setenv("SR_LN_INLINE", "1")
         y, p = run_unet(sd, cfg, dtype, T(d["x"]), T(d["t"]), T(d["ctx"]), inject=inject)
         n_blocks = count(base, L.OP_LAYERNORM) // 3
-        assert count(p, L.OP_LAYERNORM) == (n_blocks if inject is not None else 0)      # one small LayerNorm per injected block
+        assert count(p, L.OP_LAYERNORM) == 0
+        assert count(p, L.OP_LAYERNORM_GATHER) == (n_blocks if inject is not None else 0)   # the injected frame: picked + normalised
+        assert count(p, L.OP_GATHER_ROWS) == 0
         n_inline = sum(1 for i in range(p["step"].n) if p["step"].ops[i].kind == L.OP_IGEMM and p["step"].ops[i].u.igemm.ln_inline)
         assert n_inline == (3 if inject is not None else 5) * n_blocks                  # q, q2, ff1 (+ k, v without injection)
         ref = T(d[key])

@@ -46,7 +46,7 @@ def run(prefetch):
         eb = [torch.cuda.Event(enable_timing=True) for _ in range(plan.n)]
         torch.cuda.synchronize()
         for i in range(plan.n):
-            if ops[i].kind >= L.OP_FORK:
+            if ops[i].kind in (L.OP_FORK, L.OP_JOIN):
                 continue
             ea[i].record()
             lib.sr_plan_run(ones[i], 1, O.stream_ptr())
@@ -59,7 +59,7 @@ def run(prefetch):
                     wt[j].view(torch.int16).sum(dtype=torch.int32)
         torch.cuda.synchronize()
         for i in range(plan.n):
-            if ops[i].kind < L.OP_FORK:
+            if ops[i].kind not in (L.OP_FORK, L.OP_JOIN):
                 tot[i] += ea[i].elapsed_time(eb[i]) * 1e3 / reps
     return tot
 

@@ -42,7 +42,7 @@ if SEQ:
         torch.cuda.synchronize()
         evs[0].record()
         for i in range(plan.n):
-            if plan.ops[i].kind < L.OP_FORK:
+            if plan.ops[i].kind not in (L.OP_FORK, L.OP_JOIN):
                 lib.sr_plan_run(ones[i], 1, O.stream_ptr())
             evs[i + 1].record()
         torch.cuda.synchronize()
@@ -56,7 +56,7 @@ for i in range(plan.n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         one = (L.Op * 1)(op)
         one[0].lane = 0
-        if op.kind >= L.OP_FORK:
+        if op.kind in (L.OP_FORK, L.OP_JOIN):
             continue
         lib.sr_plan_run(one, 1, O.stream_ptr())
         e0.record()
