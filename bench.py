@@ -392,7 +392,7 @@ def main():
                            "views_per_call": a.views, "denoise_steps": a.denoise_steps, "resolution": res, "parallelism": ("one group view-sharded x%d" if shard is not None else "view-group replicas x%d") % world,
                            "calls_in_flight_per_gpu": inflight, "controlnets": ["depth", "normal"] if a.controlnets else []},
                 "exposed_comm_ms_per_denoise_step": None if comm_ms is None else round(comm_ms / max(steps * a.denoise_steps, 1), 4),
-                "value_1_in_flight": None if one_at_a_time is None else round(one_at_a_time * world, 4),
+                "value_1_in_flight": None if one_at_a_time is None else round(one_at_a_time * (1 if shard is not None else world), 4),
                 "replicas": replicas, "shard_error": shard_error,
                 "check": check, "roofline": roof, "cpu_baseline": cpu}
 
@@ -418,8 +418,17 @@ def main():
             rep = dict(dt=dtr, steps=nr, inflight=nfl, check=check_frames(pipe_r, None), roof=roofline(pipe_r, None) if rank == 0 else None)
             del fl
 
+    s1 = {}                                                   # the finished one-call-at-a-time sharded measurement, once there is one
+
     def fallback(err):
-        """the sharded phase failed or stalled: rank 0 prints the replica measurement as the line (weak scaling, no collective)"""
+        """the sharded phase failed or stalled: rank 0 prints what HAS been measured -- the sharded line without calls in flight when
+        only the in-flight phase went wrong, else the replica measurement (weak scaling, no collective)"""
+        if s1:
+            if rank == 0:
+                out_ = dict(s1["line"])
+                out_["shard_inflight_error"] = err
+                print(json.dumps(out_), flush=True)
+            return 0
         if rank == 0 and rep is not None:
             print(json.dumps(line(replicas["value"], rep["dt"], rep["steps"], None, rep["inflight"], None, None, replicas, rep["check"],
                                   rep["roof"], None, shard_error=err)), flush=True)
@@ -486,10 +495,31 @@ def main():
                 pipe.call(timings=tm)
                 print("stage breakdown (ms, synchronised): " + json.dumps({k: round(v, 2) for k, v in tm.items()}), file=sys.stderr)
             roof = roofline(pipe, shard) if rank == 0 else None
+            shard_inflight = None
+            if (shard is not None and world > 1 and inflight == 1 and a.inflight > 1 and not a.roofline_only
+                    and os.environ.get("SR_BENCH_SHARD_INFLIGHT_PHASE", "1") == "1"):
+                # ---- second sharded phase: the SAME group sharding with `--inflight` calls in flight per rank, every slot on its own
+                # communicator -- what the one-GPU headline does too (3 calls in flight), so the strong-scaling curve compares like with
+                # like.  Rehearsed over 2-rank gloo and a one-rank RCCL group only (several RCCL communicators in flight on a node is
+                # what a node has to show), hence AFTER the plain sharded measurement is complete: if this phase raises or stalls, the
+                # line printed is the plain sharded one with the failure in `shard_inflight_error`.
+                sync()
+                s1["line"] = line(frames / dt, dt, a.steps, shard, 1, comm_ms, None, replicas, check, roof, None)
+                fl2 = InflightCalls(pipe, a.inflight)
+                fl2.warm(max(1, a.warmup))
+                sync()
+                t2 = time.perf_counter()
+                fl2.run(a.steps)
+                sync()
+                dt2 = max_over_ranks(max(time.perf_counter() - t2, 1e-9))
+                shard_inflight = {"value": round(frames / dt2, 4), "ms_per_step": round(dt2 / max(a.steps, 1) * 1e3, 2),
+                                  "calls_in_flight_per_gpu": a.inflight}
+                if dt2 < dt:                                  # the headline keeps calls in flight, as at N = 1
+                    one_at_a_time, dt, inflight, comm_ms = frames / dt, dt2, a.inflight, None
             if dist is not None:
                 sync()                                        # every rank has finished its sharded phase before the line goes out
     except Exception as e:                                    # noqa: BLE001 -- a failing sharded phase must not cost the line
-        if not (want_shard and rep is not None):
+        if not (want_shard and (rep is not None or s1)):
             raise
         import traceback
         traceback.print_exc()
@@ -500,7 +530,10 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
-        print(json.dumps(line(frames / dt, dt, a.steps, shard, inflight, comm_ms, one_at_a_time, replicas, check, roof, cpu)), flush=True)
+        out = line(frames / dt, dt, a.steps, shard, inflight, comm_ms, one_at_a_time, replicas, check, roof, cpu)
+        if shard_inflight is not None:
+            out["shard_calls_in_flight"] = shard_inflight
+        print(json.dumps(out), flush=True)
     if dist is not None:
         with RegionGuard("process-group teardown", 60, code=0):
             dist.destroy_process_group()

@@ -52,9 +52,9 @@ def test_region_guard_leaves_the_process():
 @pytest.mark.gpu
 def test_bench_gpus_2_self_launch_over_gloo_on_one_gpu():
     """`python bench.py --gpus 2`: two fresh rank processes sharing the test GPU (gloo, host-staged collectives), the 8-view group
-    sharded 4 + 4, the replica figure measured first and printed beside the sharded one"""
+    sharded 4 + 4, the replica figure measured first and printed beside the sharded one, then the same sharding with two calls in flight"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-                        "--denoise-steps", "4", "--inflight", "1"],
+                        "--denoise-steps", "4", "--inflight", "2"],
                        env=_env(SR_DIST_BACKEND="gloo", SR_BENCH_LIMIT_S="900"), capture_output=True, text=True, timeout=1000)
     assert r.returncode == 0, r.stderr[-4000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -62,3 +62,6 @@ def test_bench_gpus_2_self_launch_over_gloo_on_one_gpu():
     assert d["config"]["parallelism"] == "one group view-sharded x2"
     assert d["replicas"] is not None and d["replicas"]["parallelism"] == "view-group replicas x2" and d["replicas"]["value"] > 0
     assert d["check"]["frames_finite"] and d["value"] > 0
+    # the second sharded phase (two sharded calls in flight per rank, every slot its own process group) ran after the plain one
+    assert d.get("shard_inflight_error") is None and d["shard_calls_in_flight"]["calls_in_flight_per_gpu"] == 2
+    assert d["shard_calls_in_flight"]["value"] > 0
