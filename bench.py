@@ -445,6 +445,9 @@ def main():
             pipe = build(shard)
             if a.roofline_only:                               # no calls: just the UNet step plan (as a sampling run builds it)
                 a.warmup, a.steps, a.no_cpu_baseline = 0, 0, True
+                if pipe.controls:                             # (the ControlNet hint encoders run in _load_ctx: give them the G-buffer planes)
+                    pipe.render_views()
+                    pipe.runner.set_control_hints(pipe.control_hints())
                 p_ = pipe.runner._ensure_plan([min(3, 2 * a.views - 1)])
                 pipe.runner._load_ctx(p_)
                 # real activations in every buffer the igemm replay reads: a mid-schedule latent through the WHOLE plan once (a replay

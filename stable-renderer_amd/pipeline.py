@@ -331,15 +331,19 @@ class FramePipeline:
                     self.shard.overlap_step(ctx.noise, lambda full: idx_all.step(full, corr.step_finished_inject_ratio),
                                             handle=pending.pop(ctx.step_index, None))
         if self.controls:
-            planes = {"depth": lambda: self.normal_depth[..., 3:4].expand(-1, -1, -1, 3), "normal": lambda: self.normal_depth[..., :3],
-                      "color": lambda: self.colors, "canny": lambda: self.canny}
-            self.runner.set_control_hints([planes[k]().permute(0, 3, 1, 2).float().contiguous() for k, _ in self.controls])
+            self.runner.set_control_hints(self.control_hints())
         samples, inj = self.runner.sample(ed.noise_maps["noise"], self.steps, self.sampler, self.scheduler,
                                           latent_image=ed.noise_maps["samples"], inject_n_rand=n_rand, step_callback=cb,
                                           rng_turn=rng_turn, pre_step_callback=pre)
         if isinstance(corr, OverlapCorresponder) and inj is not None:
             corr._random_frame_indices = torch.tensor(inj)
         return samples
+
+    def control_hints(self):
+        """the G-buffer planes of the rendered views as ControlNet hints, one (N,3,H,W) tensor per attached net"""
+        planes = {"depth": lambda: self.normal_depth[..., 3:4].expand(-1, -1, -1, 3), "normal": lambda: self.normal_depth[..., :3],
+                  "color": lambda: self.colors, "canny": lambda: self.canny}
+        return [planes[k]().permute(0, 3, 1, 2).float().contiguous() for k, _ in self.controls]
 
     def decode(self, samples):
         self.vplan["z"].copy_(samples)
