@@ -184,6 +184,85 @@ def _lists_body(rank, world):
     return (rank, err, (mine_g - mine).abs().max().item(), inj0, inj1, inj2, (seed0, seed1, seed2))
 
 
+def _headline_worker(rank, world, port, q):
+    _guarded(_headline_body, rank, world, port, q)
+
+
+def _headline_body(rank, world):
+    """the HEADLINE workload view-sharded over two ranks -- 8 overlapped views x 20 ddim steps at 512^2, full SD1.5-shaped UNet + VAE,
+    four views per rank -- against the REFERENCE's own run of it (tests/golden/full_bench8_20.npz): latent all-gather per overlap
+    step, K/V-source broadcast per transformer block, frames gathered to rank 0"""
+    import hashlib
+    import json
+    from stable_renderer_amd import ops as O
+    from stable_renderer_amd import synth
+    from stable_renderer_amd.corresponder import OverlapCorresponder
+    from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes
+    from stable_renderer_amd.parallel import ViewShard
+    from stable_renderer_amd.pipeline import BakeBallScene, FramePipeline
+    from stable_renderer_amd.types import LATENT
+    from stable_renderer_amd.unet import SD15_CFG, UNet
+    from stable_renderer_amd.vae import VAEDecoder
+    torch.cuda.set_device(0)
+    gold = os.path.join(ROOT, "tests", "golden")
+    if os.path.exists(os.path.join(gold, "tune_table.json")):
+        O.load_tune_table(os.path.join(gold, "tune_table.json"))
+    g = np.load(os.path.join(gold, "full_bench8_20.npz"))
+    m = json.loads(bytes(g["meta"]).decode())
+    ns, norms = unet_names_shapes(SD15_CFG)
+    vns, vnorms = vae_decoder_names_shapes()
+    sd_u = synth.synth_state_dict(ns, seed=m["unet_seed"], norm_names=norms)
+    sd_v = synth.synth_state_dict(vns, seed=m["vae_seed"], norm_names=vnorms)
+    ctx = lambda seed: torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(seed))
+    out = {}
+    for name, dtype in (("f32", torch.float32), ("f16", torch.float16)):
+        sh = ViewShard(m["views"])
+        corr = OverlapCorresponder(step_finished_inject_ratio=m["ratio"], step_finished_stop_inject_timestep=m["stop"],
+                                   pre_attn_inject_num_random_frames=1)
+        pipe = FramePipeline(UNet(sd_u, SD15_CFG, dtype=dtype), VAEDecoder(sd_v, dtype=dtype), BakeBallScene(512, 512, k=6),
+                             n_views=m["views"], steps=m["steps"], cfg=m["cfg"], sampler=m["sampler"], scheduler=m["scheduler"],
+                             corresponder=corr, use_graph=True, shard=sh)
+        pipe.set_prompt(ctx(m["pos_seed"]), ctx(m["neg_seed"]))
+        ed = pipe.render_views()
+        ids_all = pipe._ids_all.tensor.cpu().numpy()                                      # every rank holds every view's ids
+        assert hashlib.sha256(np.ascontiguousarray(ids_all).tobytes()).hexdigest() == bytes(g["ids_sha"]).decode()
+        gn = torch.from_numpy(g["noise"])[sh.slice]
+        assert torch.allclose(ed.noise_maps["noise"].cpu(), gn, atol=3e-3, rtol=2e-3)
+        ed.noise_maps = LATENT(samples=torch.zeros_like(gn).cuda(), noise=gn.cuda())
+        torch.manual_seed(m["rng_seed"])
+        samples = pipe.diffuse(ed)
+        frames = sh.gather_frames_to_rank0(pipe.decode(samples))
+        lat = sh.gather_latents(samples)
+        torch.cuda.synchronize()
+        inj = [int(i) for i in pipe.corresponder._random_frame_indices]
+        res = dict(inj=inj)
+        if rank == 0:
+            ref_s, ref_img = torch.from_numpy(g["samples"]), torch.from_numpy(g["img_sub"]).float()
+            mse = float(((frames.cpu()[:, ::4, ::4].double() - ref_img.double()) ** 2).mean())
+            res.update(psnr=99.0 if mse == 0 else 10.0 * np.log10(1.0 / mse),
+                       rel=(lat.cpu() - ref_s).abs().max().item() / ref_s.abs().max().item())
+        out[name] = res
+        del pipe
+        torch.cuda.empty_cache()
+    return dict(out=out, inj_ref=g["inj"].tolist())
+
+
+@pytest.mark.timeout(1200)
+def test_two_rank_shard_of_the_headline_workload_vs_reference():
+    """row (e) at the headline shape and length against the reference itself: the 8-view 20-step call sharded 4 + 4 over two ranks
+    (gloo, both on the test GPU) reproduces the reference's decoded frames -- PSNR >= 40 dB / latent 1e-3 at fp32, the fp16 floor of
+    the unsharded run (54 dB) at fp16 -- with the same injected frame on both ranks as the reference drew"""
+    res = _run_ranks(_headline_worker, 2, 31700 + (os.getpid() % 1000), timeout=1100)
+    for r in res:
+        for name in ("f32", "f16"):
+            assert r["out"][name]["inj"] == r["inj_ref"], (r["out"][name]["inj"], r["inj_ref"])
+    r0 = res[0]["out"]
+    print(f"headline workload sharded over 2 ranks vs the reference: fp32 {r0['f32']['psnr']:.1f} dB (latent rel {r0['f32']['rel']:.2e}), "
+          f"fp16 {r0['f16']['psnr']:.1f} dB (latent rel {r0['f16']['rel']:.2e})")
+    assert r0["f32"]["psnr"] >= 40.0 and r0["f32"]["rel"] < 1e-3, r0["f32"]
+    assert r0["f16"]["psnr"] >= 54.0, r0["f16"]
+
+
 @pytest.fixture(scope="module")
 def two_ranks():
     return _run_ranks(_all_worker, 2, 29700 + (os.getpid() % 1000), timeout=900)
