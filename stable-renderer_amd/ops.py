@@ -157,6 +157,16 @@ def save_tune_table(path):
         _json.dump({_json.dumps([int(x) for x in k]): list(v) for k, v in sorted(_TUNED.items())}, f, indent=0)
 
 
+# SR_AUTOTUNE_TABLES: read-only tables (os.pathsep separated) merged at import -- the multi-process tests pin the per-rank shapes this
+# way (tests/golden/tune_table_ranks.json), each rank being a fresh process that would otherwise time them again.
+for _tbl in filter(None, os.environ.get("SR_AUTOTUNE_TABLES", "").split(os.pathsep)):
+    if os.path.exists(_tbl):
+        load_tune_table(_tbl)
+if os.environ.get("SR_AUTOTUNE_DUMP"):                     # development: every process leaves its table as <prefix>.<pid>.json
+    import atexit as _atexit
+    _atexit.register(lambda: save_tune_table("%s.%d.json" % (os.environ["SR_AUTOTUNE_DUMP"], os.getpid())))
+
+
 _CANDIDATES = ((0, 0), (0, -1), (1, -1), (2, 0), (2, -1), (2, 2), (2, 3), (2, 4), (2, 6), (2, 8), (3, 0), (3, -1), (3, 2), (3, 3), (3, 4), (3, 6), (3, 8), (4, -1), (5, -1), (6, -1), (7, -1), (8, -1), (9, -1), (10, -1), (11, -1), (12, -1),
                (13, -1), (14, -1), (14, 2), (14, 3), (14, 4), (14, 5), (15, -1), (15, 2), (15, 3), (15, 4), (15, 5))
 

@@ -55,7 +55,8 @@ def test_bench_gpus_2_self_launch_over_gloo_on_one_gpu():
     sharded 4 + 4, the replica figure measured first and printed beside the sharded one, then the same sharding with two calls in flight"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
                         "--denoise-steps", "4", "--inflight", "2"],
-                       env=_env(SR_DIST_BACKEND="gloo", SR_BENCH_LIMIT_S="900"), capture_output=True, text=True, timeout=1000)
+                       env=_env(SR_DIST_BACKEND="gloo", SR_BENCH_LIMIT_S="900",
+                                SR_AUTOTUNE_TABLES=os.path.join(ROOT, "tests", "golden", "tune_table_ranks.json")), capture_output=True, text=True, timeout=1000)
     assert r.returncode == 0, r.stderr[-4000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["shard_error"] is None

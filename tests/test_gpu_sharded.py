@@ -33,10 +33,15 @@ def _guarded(body, rank, world, port, q, backend="gloo"):
         q.put((rank, "error", traceback.format_exc()))
 
 
+RANK_TABLES = os.pathsep.join(os.path.join(ROOT, "tests", "golden", n) for n in ("tune_table.json", "tune_table_ranks.json"))
+
+
 def _run_ranks(target, world, port, timeout=400):
     """start `world` ranks, fail fast when one dies or reports an error, never leave children behind"""
     import queue as _q
     import time
+    # every rank is a fresh process: the per-rank layer shapes are pinned (read-only tables) instead of being timed again by each
+    os.environ.setdefault("SR_AUTOTUNE_TABLES", RANK_TABLES)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
