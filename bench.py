@@ -36,11 +36,8 @@ def cpu_baseline():
     from stable_renderer_amd import synth
     from stable_renderer_amd.model_shapes import unet_names_shapes, vae_decoder_names_shapes
     from stable_renderer_amd.unet import SD15_CFG
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))            # the GPU box grants a 16-CPU share per GPU; more threads only thrash
+    from stable_renderer_amd.hostcpu import cpu_share
+    cores = max(1, min(cpu_share(), 16))      # affinity mask AND cgroup quota (the GPU box: 256 visible, 16 granted per GPU)
     torch.set_num_threads(cores)
     ns, norms = unet_names_shapes(SD15_CFG)
     sd = synth.synth_state_dict(ns, seed=0, norm_names=norms)
@@ -124,9 +121,11 @@ def launch_ranks(a, argv):
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
+    from stable_renderer_amd.hostcpu import cpu_share
+    threads = os.environ.get("OMP_NUM_THREADS") or str(max(1, cpu_share() // n))      # the ranks share this process's CPU quota
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, OMP_NUM_THREADS=threads, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
@@ -241,6 +240,8 @@ def main():
             else:
                 dist.init_process_group(backend)
     torch.cuda.set_device(local)
+    from stable_renderer_amd.hostcpu import limit_torch_threads
+    limit_torch_threads(world)                                # start-up (weight synthesis, packing) is CPU work: fit the CPU quota
     from stable_renderer_amd import _lib as L
     from stable_renderer_amd import ops as O
     from stable_renderer_amd.pipeline import InflightCalls, build_sd15_pipeline
@@ -270,6 +271,12 @@ def main():
         extra = dict(W=1024, H=1024, unet_cfg=dict(SDXL_CFG))
         a.inflight, a.no_cpu_baseline = 1, True               # the CPU port of this size takes hours: not a bounded sample
     cdev = "cuda" if backend == "nccl" else "cpu"
+    t_start = time.perf_counter()
+
+    def note(msg):
+        """progress on stderr (rank 0): a default run takes minutes, most of it building weights and the CPU baseline"""
+        if rank == 0:
+            print("[bench %6.1f s] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     def sync():
         torch.cuda.synchronize()
@@ -285,6 +292,7 @@ def main():
         return float(tt.item())
 
     def build(shard):
+        note("building the %s pipeline (random-init weights, launch plans)" % ("view-sharded" if shard is not None else "one-GPU"))
         pipe_ = build_sd15_pipeline(dtype=dtype, n_views=a.views, steps=a.denoise_steps, cfg=8.0, use_graph=not a.no_graph,
                                     device="cuda:%d" % local, shard=shard, controls=controls, **extra)
         if sdxl:
@@ -307,6 +315,7 @@ def main():
             def run(self):
                 for p_ in self.plans:
                     p_.run()
+        note("roofline: igemm launches of one UNet evaluation replayed under events")
         sched = pipe_.runner._plan.get("schedule") or []
         plans = [r[1] for r in sched if r[0] == "run"] or [pipe_.runner._plan["step"]]
         plan = _Seq(plans)
@@ -350,6 +359,7 @@ def main():
     def check_frames(pipe_, shard):
         """outside the timed region: the decoded frames of one more call must be finite; their checksum is compared with the value
         recorded beside the pinned tuner table (tests/golden/bench_check.json) when this run used that table"""
+        note("result check: one more call, frames finite + checksum")
         pipe_.frame0 = 0                                      # the check call is a function of (scene, seed, kernels) alone:
         torch.manual_seed(4321)                               # frames 0..N-1, a fixed RNG state (sampling never reads the corr-map)
         img = pipe_.call()
@@ -407,8 +417,10 @@ def main():
             nfl = 1 if sdxl else max(1, a.inflight)
             nr = max(nfl, min(a.steps, 2 * nfl))
             fl = InflightCalls(pipe_r, nfl)
+            note("replica phase: warm-up, %d calls in flight" % nfl)
             fl.warm(1)
             sync()
+            note("replica phase: %d timed calls" % nr)
             t1 = time.perf_counter()
             fl.run(nr)
             sync()
@@ -461,17 +473,21 @@ def main():
             inflight = max(1, a.inflight) if ((shard is None or a.shard_inflight) and not a.roofline_only) else 1
             if inflight > 1:
                 fl = InflightCalls(pipe, inflight)
+                note("warm-up: %d call(s) on each of %d slots (plans built and captured here)" % (a.warmup, inflight))
                 fl.warm(a.warmup)                             # every slot builds / tunes / captures alone, W calls each
                 sync()
+                note("timed region: %d calls, %d in flight" % (a.steps, inflight))
                 t0 = time.perf_counter()
                 fl.run(a.steps)                               # exactly K calls, call c on slot c % inflight
                 sync()
             else:
+                note("warm-up: %d call(s) (plans built and captured here)" % a.warmup)
                 for _ in range(a.warmup):
                     pipe.call()
                 sync()
                 if shard is not None:
                     pipe.runner.exposed_comm_ms()             # drop the warm-up's records
+                note("timed region: %d calls, one at a time" % a.steps)
                 t0 = time.perf_counter()
                 for _ in range(a.steps):
                     pipe.call()
@@ -486,6 +502,7 @@ def main():
             if not a.roofline_only:
                 if inflight > 1:
                     n1 = max(1, min(a.steps, 4))
+                    note("outside the timed region: %d calls one at a time" % n1)
                     sync()
                     t1 = time.perf_counter()
                     for _ in range(n1):
@@ -509,6 +526,7 @@ def main():
                 sync()
                 s1["line"] = line(frames / dt, dt, a.steps, shard, 1, comm_ms, None, replicas, check, roof, None)
                 fl2 = InflightCalls(pipe, a.inflight)
+                note("second sharded phase: %d calls in flight per rank" % a.inflight)
                 fl2.warm(max(1, a.warmup))
                 sync()
                 t2 = time.perf_counter()
@@ -531,7 +549,9 @@ def main():
         os._exit(code)                                        # the other ranks may sit in a collective this rank will never join
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        note("CPU baseline: the oracle on a bounded sample of the same workload")
         cpu = cpu_baseline()
+    note("done")
     if rank == 0:
         out = line(frames / dt, dt, a.steps, shard, inflight, comm_ms, one_at_a_time, replicas, check, roof, cpu)
         if shard_inflight is not None:

@@ -36,11 +36,11 @@ def synth_state_dict(names_shapes, seed: int = 0, gain: float = 1.0, norm_names=
             fan_in = 1
             for d in s[1:]:
                 fan_in *= d
-            out[n] = torch.randn(s, generator=g, dtype=torch.float32) * (gain * fan_in ** -0.5)
+            out[n] = torch.randn(s, generator=g, dtype=torch.float32).mul_(gain * fan_in ** -0.5)
         elif n in norm_names:
-            out[n] = 1.0 + 0.1 * torch.randn(s, generator=g, dtype=torch.float32)
+            out[n] = torch.randn(s, generator=g, dtype=torch.float32).mul_(0.1).add_(1.0)
         else:
-            out[n] = 0.05 * torch.randn(s, generator=g, dtype=torch.float32)
+            out[n] = torch.randn(s, generator=g, dtype=torch.float32).mul_(0.05)
     return out
 
 

@@ -32,6 +32,8 @@ def pytest_configure(config):
 
 def pytest_sessionstart(session):
     config = session.config
+    from stable_renderer_amd.hostcpu import limit_torch_threads
+    limit_torch_threads()                                     # the oracle is torch-CPU: fit its pool to the cgroup quota (and the children's)
     period = float(os.environ.get("SR_TEST_HEARTBEAT_S", "60"))
     if period > 0 and _BEAT["stop"] is None:
         import threading
