@@ -159,6 +159,10 @@ class InflightCalls:
     def __init__(self, pipe, inflight=2):
         self.pipes = [pipe] + [pipe.spawn(i) for i in range(1, inflight)]
         self.streams = [torch.cuda.Stream(device=pipe.unet.device) for _ in self.pipes]
+        if len(self.pipes) > 1:
+            for p in self.pipes:                             # view shard: with calls in flight the host threads are the bound --
+                if p.shard is not None and p.runner.graph_segments is None:     # replay the plan segments as hipGraphs
+                    p.runner.graph_segments = True           # (DiffusionRunner._sharded_eval; SR_SHARD_GRAPH_SEGMENTS overrides)
 
     def warm(self, calls=1):
         """build plans / tune tiles / capture graphs one pipeline at a time (timing-based tuning and graph capture want the GPU

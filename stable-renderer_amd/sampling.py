@@ -25,7 +25,9 @@ SCHEDULER_NAMES = ["normal", "karras", "exponential", "sgm_uniform", "simple", "
 SAMPLER_NAMES = ["euler", "ddim", "ddpm", "lcm"]
 
 
-_GRAPH_SEGMENTS = os.environ.get("SR_SHARD_GRAPH_SEGMENTS", "0") == "1"
+# view shard: replay the cut plan segments as hipGraphs?  "1" / "0" decide; unset = eagerly for one call at a time, as graphs once
+# calls are in flight (pipeline.InflightCalls turns it on): see DiffusionRunner._sharded_eval
+_GRAPH_SEGMENTS = {"1": True, "0": False}.get(os.environ.get("SR_SHARD_GRAPH_SEGMENTS", ""))
 
 class ModelSamplingDiscrete:
     def __init__(self, linear_start=0.00085, linear_end=0.012, timesteps=1000):
@@ -476,11 +478,14 @@ class DiffusionRunner:
         ``time_comm``) accumulates the time the compute stream spent stalled in those waits = the EXPOSED communication."""
         from . import parallel as PAR
         sched = p["schedule"]
-        # The 33 segments of an evaluation are launched eagerly (sr_plan_run) unless SR_SHARD_GRAPH_SEGMENTS=1 / runner.graph_segments: a hipGraphLaunch per
-        # segment costs more start-up latency than the ~12 kernels of a segment save in launch gaps -- measured as one rank of a
-        # shard (world-1 RCCL group, same box): 154.2 -> 148.1 ms per call at one view per rank, 197.3 -> 191.0 at two, 277.0 ->
-        # 270.0 at four.
-        use_graph = self.use_graph and self.graph_segments
+        # One call at a time, the 33 segments of an evaluation are launched eagerly (sr_plan_run): a hipGraphLaunch per segment costs
+        # more start-up latency than the ~12 kernels of a segment save in launch gaps -- measured as one rank of a shard (world-1
+        # RCCL group, same box): 145.0 -> 138.6 ms per call at one view per rank, 187.3 -> 179.7 at two.  With calls in flight it
+        # is the other way round: three host threads launching 6 800 kernels per call each are what bounds the rank (the B = 2
+        # evaluations of different calls do overlap on the GPU: 5.96 -> 3.99 ms per evaluation side by side), and a graph launch
+        # per segment takes the host out of the way: 110.5 -> 97.7 ms per call at one view per rank with three in flight, 153.2 ->
+        # 138.7 at two.  graph_segments: None = this rule (InflightCalls sets True), True / False = SR_SHARD_GRAPH_SEGMENTS.
+        use_graph = self.use_graph and bool(self.graph_segments)
         if use_graph and not p.get("_segments_captured"):            # (per plan: conditioning lists run several plans per step)
             torch.cuda.current_stream().synchronize()
             for kind, *rest in sched:                       # all captures up front: none while a collective is in flight

@@ -840,3 +840,24 @@ def test_sampler_raises_when_the_device_side_injected_index_is_bad():
     r._ensure_plan = orig
     out2, _ = r.sample(noise, 2, "ddim", "normal", inject_n_rand=1)       # the flag was cleared: the runner stays usable
     assert torch.isfinite(out2).all()
+
+
+@pytest.mark.gpu
+def test_stream_ptr_follows_the_current_stream_of_the_thread(ops):
+    """ops.stream_ptr() (torch's raw-stream binding) is the stream `with torch.cuda.stream(...)` made current, per thread"""
+    import threading
+    O = ops
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    assert (O.stream_ptr().value or 0) == torch.cuda.current_stream().cuda_stream
+    with torch.cuda.stream(s1):
+        assert O.stream_ptr().value == s1.cuda_stream
+        seen = []
+
+        def other():
+            with torch.cuda.stream(s2):
+                seen.append(O.stream_ptr().value)
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen == [s2.cuda_stream]
+        assert O.stream_ptr().value == s1.cuda_stream

@@ -15,6 +15,9 @@ from stable_renderer_amd.pipeline import build_sd15_pipeline  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "unet"
 dtype = torch.float16 if (len(sys.argv) < 3 or sys.argv[2] == "f16") else torch.float32
 VIEWS = int(os.environ.get("SR_VIEWS", "8"))
+_tt = os.path.join(ROOT, "tests", "golden", "tune_table.json")
+if os.path.exists(_tt) and os.environ.get("SR_BENCH_TUNE", "pinned") == "pinned":
+    O.load_tune_table(_tt)                                   # the table bench.py runs on
 pipe = build_sd15_pipeline(dtype=dtype, use_graph=False, n_views=VIEWS)
 if which == "unet":
     p = pipe.runner._ensure_plan([min(3, 2 * VIEWS - 1)])
