@@ -116,7 +116,12 @@ typedef struct {
                              applies out = rstd * (x . W'^T) - rstd * mean * colsum + bias' -- no LayerNorm pass, no statistics pass, no
                              statistics tensor.  Needs colsum, row_stats == NULL, KH 1, stride 1, one source; never split over K        */
   float ln_eps;           /* epsilon of that LayerNorm (1e-5 in BasicTransformerBlock)                                                  */
-  int32_t reserved_;
+  int32_t tile_order;     /* which operand an XCD keeps in ITS L2 (workgroups are dealt to the 8 XCDs round-robin; each XCD gets a contiguous
+                             run of the tile sequence): 0 = rows first -- an XCD works through a band of M-tiles and every N-tile of them:
+                             the activations cross the fabric once, the packed weights once per XCD (right for the 64x64 / 32x32 levels,
+                             whose weights are small); 1 = columns first -- an XCD takes a band of N-tiles and every M-tile of them: the
+                             weights cross once, the activations once per XCD (the 16x16 / 8x8 levels: 29.5-59 MB of weights against
+                             2.6-21 MB of activations per layer).  Same values either way; tile 8 ignores it.                          */
 } sr_igemm_args;
 #define SR_IGEMM_SPLIT_COUNTERS 4096
 #define SR_IGEMM_GROUP_MAX 4

@@ -23,7 +23,7 @@ class IgemmArgs(C.Structure):
                 ("KH", i32), ("stride", i32), ("upsample", i32), ("act", i32), ("transpose_out", i32), ("ldt", i32),
                 ("out_f32", i32), ("dtype", i32), ("scale", f32), ("rowvec_ld", i32), ("workspace", vp),
                 ("workspace_bytes", C.c_int64), ("row_stats", vp), ("colsum", vp), ("tile", i32), ("split", i32), ("pad_br", i32),
-                ("prefetch", vp), ("prefetch_bytes", C.c_int64), ("up_h", i32), ("up_w", i32), ("split_counters", vp), ("group", i32), ("ln_inline", i32), ("ln_eps", f32), ("reserved_", i32)]
+                ("prefetch", vp), ("prefetch_bytes", C.c_int64), ("up_h", i32), ("up_w", i32), ("split_counters", vp), ("group", i32), ("ln_inline", i32), ("ln_eps", f32), ("tile_order", i32)]
 
 
 class GroupNormArgs(C.Structure):

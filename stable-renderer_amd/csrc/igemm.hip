@@ -402,7 +402,8 @@ __device__ __forceinline__ void igemm_body(const sr_igemm_args& p, const int M, 
                       __builtin_amdgcn_readfirstlane(sr_lds_addr(smem_all) + wv * 256));
   }
   const int wg = tile0 + sr_xcd_remap(bid, nwg);             // this launch covers tiles [tile0, tile0 + nwg)
-  const int mt = wg / NT, nt = wg - mt * NT;
+  int mt, nt;
+  sr_tile_of(wg, NT, (M + BM - 1) / BM, p.tile_order, mt, nt);
   const int m0 = mt * BM, n0 = nt * BN;
   if constexpr (VECPRE) {
     // [bias n0..n0+BN) | colsum n0..n0+BN)] -> LDS, 16 bytes per lane; absent rows / columns past N come from the zero page.
@@ -900,7 +901,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sr_igemm_args 
   const int tile_l = blockIdx.x / FR, fr = blockIdx.x - tile_l * FR;
   const int tn = fr / TM, tm = fr - tn * TM;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c16 = lane & 15, g4 = lane >> 4;
-  const int wg = tile0 + tile_l, mt = wg / NT, nt = wg - mt * NT;
+  const int wg = tile0 + tile_l;
+  int mt, nt;
+  sr_tile_of(wg, NT, (M + BM - 1) / BM, p.tile_order, mt, nt);
   const int m = mt * BM + (wv >> 1) * (BM / 2) + tm * 16 + c16;
   const int n = nt * BN + (wv & 1) * (BN / 2) + tn * 16 + 4 * g4;
   const int N = p.N;
@@ -1323,6 +1326,7 @@ static int igemm_check(const sr_igemm_args* a, int* M_, int* Ho_, int* Wo_) {
   if (a->ln_inline && (a->row_stats || !a->colsum)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: ln_inline takes colsum and no row_stats");
   if ((a->row_stats || a->ln_inline) && (a->KH != 1 || a->stride != 1 || a->upsample || a->C2)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: folded LayerNorm is for 1x1 single-source layers");
   if (a->tile < 0 || a->tile > 15 || a->split < -1 || a->split == 1 || a->split > 16) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile=%d split=%d", a->tile, a->split);
+  if (a->tile_order != 0 && a->tile_order != 1) SR_FAIL(SR_ERR_INVALID, "sr_igemm: tile_order=%d (0 rows first, 1 columns first)", a->tile_order);
   int Ho, Wo;
   if (a->upsample && ((a->up_h > 0) != (a->up_w > 0))) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w go together");
   if (!a->upsample && (a->up_h || a->up_w)) SR_FAIL(SR_ERR_INVALID, "sr_igemm: up_h / up_w without upsample");

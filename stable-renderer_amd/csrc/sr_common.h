@@ -115,5 +115,12 @@ __device__ __forceinline__ int sr_xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// tile sequence number -> (M-tile, N-tile): rows first (an XCD's contiguous run covers whole bands of M-tiles: activations stay in
+// its L2) or columns first (bands of N-tiles: the packed weights stay) -- sr_igemm_args.tile_order
+__device__ __forceinline__ void sr_tile_of(int wg, int NT, int MT, int order, int& mt, int& nt) {
+  if (order == 1) { nt = wg / MT; mt = wg - nt * MT; }
+  else            { mt = wg / NT; nt = wg - mt * NT; }
+}
+
 static inline hipStream_t sr_stream(void* s) { return (hipStream_t)s; }
 static inline int sr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -109,7 +109,7 @@ def split_counters(device):
 
 def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C2=0, bias=None, rowvec=None,
                residual=None, act=0, transpose_out=0, ldt=0, out_f32=0, scale=1.0, dtype=None, rowvec_ld=0, tile=0, split=0, row_stats=None, colsum=None,
-               pad_br=0, up_hw=None, ln_inline=False, ln_eps=1e-5):
+               pad_br=0, up_hw=None, ln_inline=False, ln_eps=1e-5, tile_order=0):
     ar = L.IgemmArgs()
     ar.a, ar.a2, ar.w, ar.bias, ar.rowvec, ar.residual, ar.out = _p(a), _p(a2), _p(w), _p(bias), _p(rowvec), _p(residual), _p(out)
     ar.zero_page = _p(zero_page(a.device))
@@ -118,7 +118,7 @@ def igemm_args(a, w, out, B, H, W, C1, N, KH=1, stride=1, upsample=0, a2=None, C
     ar.dtype = DT[a.dtype if dtype is None else dtype]
     ar.scale = scale
     ar.rowvec_ld = rowvec_ld
-    ar.tile, ar.split, ar.pad_br = tile, split, pad_br
+    ar.tile, ar.split, ar.pad_br, ar.tile_order = tile, split, pad_br, tile_order
     ar.up_h, ar.up_w = (0, 0) if (up_hw is None or tuple(up_hw) == (2 * H, 2 * W)) else (int(up_hw[0]), int(up_hw[1]))
     ar.row_stats, ar.colsum = _p(row_stats), _p(colsum)
     ar.ln_inline, ar.ln_eps = int(bool(ln_inline)), ln_eps
@@ -234,14 +234,29 @@ def _tune_cold(ar, sig, allow_split, reps):
     for c in _CANDIDATES:
         if c in times and (best_t is None or times[c] < best_t * 0.97):
             best, best_t = c, times[c]
-    _TUNED[sig] = best
+    # sr_igemm_args.tile_order: which operand stays in an XCD's L2.  Columns first (the packed weights cross the fabric once, the
+    # activations once per XCD) only pays where the weights dwarf the activations AND the launch is a few rounds of tiles: 99.3 ->
+    # 83.3 us on the 8x8 C2560 3x3 conv of a B = 16 evaluation (59 MB of weights, 5.2 MB of activations), 58.4 -> 56.6 at C1280;
+    # at 16x16 (29.5 MB against 10.5) it LOSES 3-5 %, at 32x32 5-10 % (tools/bench_order.py).  Timed for the winner where
+    # weights > 2 x activations, kept at 3 % or better.
+    order = 0
+    w_bytes = ar.N * ar.KH * ar.KH * (ar.C1 + ar.C2) * es
+    a_bytes = ar.B * ar.H * ar.W * (ar.C1 + ar.C2) * es
+    if best_t is not None and w_bytes > 2 * a_bytes and os.environ.get("SR_TUNE_ORDER", "1") == "1":
+        ar.tile, ar.split = best
+        t0 = min(best_t, timed(3 * reps))
+        ar.tile_order = 1
+        if lib.sr_igemm(C.byref(ar), st) == 0 and timed(3 * reps) < 0.97 * t0:
+            order = 1
+        ar.tile_order = 0
+    _TUNED[sig] = best + ((1,) if order else ())
     if _TUNE_CACHE:
         import json as _json
         with open(_TUNE_CACHE, "w") as _f:
             _json.dump({_json.dumps([int(x) for x in k]): list(v) for k, v in _TUNED.items()}, _f)
     if os.environ.get("SR_AUTOTUNE_LOG"):
         print(f"[tune cold] B{ar.B} {ar.H}x{ar.W} C{ar.C1}+{ar.C2} N{ar.N} k{ar.KH} s{ar.stride} u{ar.upsample} act{ar.act} "
-              f"t{ar.transpose_out} -> tile {best[0]} split {best[1]}  {best_t * 1e3:.1f} us", flush=True)
+              f"t{ar.transpose_out} -> tile {best[0]} split {best[1]} order {order}  {best_t * 1e3:.1f} us", flush=True)
 
 
 def tune_igemm(ar, min_flops=2.0e8, reps=4, allow_split=True):
@@ -300,7 +315,8 @@ def tune_igemm(ar, min_flops=2.0e8, reps=4, allow_split=True):
         if os.environ.get("SR_AUTOTUNE_LOG"):
             print(f"[tune] B{ar.B} {ar.H}x{ar.W} C{ar.C1}+{ar.C2} N{ar.N} k{ar.KH} s{ar.stride} u{ar.upsample} act{ar.act} "
                   f"t{ar.transpose_out} -> tile {best[0]} split {best[1]}  {best_t * 1e3:.1f} us", flush=True)
-    ar.tile, ar.split = _TUNED[sig]
+    v = _TUNED[sig]                                          # (tile, split) or (tile, split, tile_order)
+    ar.tile, ar.split, ar.tile_order = v[0], v[1], (v[2] if len(v) > 2 else 0)
 
 
 GROUP_TILES = (4, 13, 3, 14, 2, 15, 9, 10)                  # tiles sr_igemm_group can run as one launch (include/sr_hip.h)

@@ -861,3 +861,36 @@ def test_stream_ptr_follows_the_current_stream_of_the_thread(ops):
         t.join()
         assert seen == [s2.cuda_stream]
         assert O.stream_ptr().value == s1.cuda_stream
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 0, 40, 3), (2, 4, 40, 3), (3, -1, 6, 1), (4, -1, 5, 3), (13, -1, 9, 1), (14, 3, 12, 3), (15, 3, 12, 1),
+                                  (9, -1, 5, 1), (7, -1, 5, 1), (0, 0, 10, 3)])
+def test_igemm_tile_order_columns_first_is_the_same_gemm(ops, dtype, case):
+    """sr_igemm_args.tile_order = 1 only changes which tile a workgroup takes (bands of N-tiles per XCD instead of bands of M-tiles):
+    bit-equal outputs for unsplit, split-K (partials + reduce) and the wide tiles, ragged M and N; any other value is refused"""
+    tile, split, ksteps, KH = case
+    if dtype == torch.float32 and tile in (7, 9):
+        pytest.skip("fp16-only tile")
+    dev = "cuda"
+    ke = ops.kelems(dtype)
+    B, H, W, C1, N = 3, 13, 11, ksteps * ke, 640 if tile in (7, 9) else 328
+    x = rnd(11, B, C1, H, W)
+    w = rnd(12, N, C1, KH, KH) * (C1 * KH * KH) ** -0.5
+    bias, resid = rnd(13, N) * 0.1, rnd(15, B, N, H, W)
+    ref = F.silu(F.conv2d(x.to(dtype).float(), w.to(dtype).float(), bias, padding=KH // 2)) + resid.to(dtype).float()
+    xa = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    wp, bp = ops.pack_conv_weight(w, dtype).to(dev), ops.pack_bias(bias).to(dev)
+    M = B * H * W
+    rs = resid.permute(0, 2, 3, 1).reshape(M, N).contiguous().to(dtype).to(dev)
+    kw = dict(KH=KH, bias=bp, residual=rs, act=1, tile=tile, split=split)
+    rows = torch.zeros(M, N, dtype=dtype, device=dev)
+    ops.igemm(xa, wp, rows, B, H, W, C1, N, **kw)
+    cols = torch.zeros(M, N, dtype=dtype, device=dev)
+    ops.igemm(xa, wp, cols, B, H, W, C1, N, tile_order=1, **kw)
+    torch.cuda.synchronize()
+    close(cols.float().cpu().reshape(B, H, W, N).permute(0, 3, 1, 2), ref, dtype, scale=ref.abs().max().item())
+    assert torch.equal(rows, cols)
+    with pytest.raises(Exception, match="tile_order"):
+        ops.igemm(xa, wp, cols, B, H, W, C1, N, tile_order=2, **kw)
