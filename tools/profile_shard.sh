@@ -6,7 +6,7 @@ export SR_SHARD_FORCE=1
 R=$GRAFT_REPO_ROOT
 for V in 8 4 2 1; do
   for FL in "--no-shard-inflight" "--inflight 3"; do
-    python3 $R/bench.py --mode shard --views $V --steps 4 --warmup 1 --no-cpu-baseline $FL 2>/dev/null | tail -1 | python3 -c "
+    python3 $R/bench.py --mode shard --views $V --steps 6 --warmup 1 --no-cpu-baseline $FL 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
 print('views/rank $V  $FL:', d['ms_per_step'], 'ms per call,', round(d['value'], 2), 'frames/s of the rank, exposed comm', d['exposed_comm_ms_per_denoise_step'], 'ms/step, UNet eval', r['unet_eval_ms'], 'ms (', r['unet_eval_launches'], 'ops ), igemm', r['achieved'], 'TF/s')"
