@@ -58,13 +58,14 @@ def cpu_baseline():
                       "scaled x4.08 to 512^2; extrapolated per view, overlap step / raster excluded (<0.1%%)" % (t_unet, t_vae256)}
 
 
-def recorded_igemm_traffic(lib_hash):
+def recorded_igemm_traffic(lib_hash, views=8):
     """HBM-side bytes of the igemm family per UNet evaluation: (2 x FETCH_SIZE + WRITE_SIZE) from the two --pmc passes of
     `bench.py --roofline-only` (tools/profile_round.sh -> profiles/rNN_igemm_traffic.json).  PMC counters cannot be read from
     inside the process, so this is a RECORDED figure: it is quoted only when the newest record was taken on kernels with the
     source hash of the library loaded now, otherwise (None, file)."""
     import glob
-    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_igemm_traffic.json")))
+    # (one record per batch size: rNN_igemm_traffic.json is the headline's B = 16, rNN_igemm_traffic_viewsV.json a V-view call's B = 2V)
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_igemm_traffic%s.json" % ("" if views == 8 else "_views%d" % views))))
     if not recs:
         return None, None
     with open(recs[-1]) as f:
@@ -334,8 +335,8 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         peak = 2500.0 if a.dtype == "f16" else 157.3
         traffic, traffic_file = None, None
-        if a.dtype == "f16" and a.views == 8 and shard is None and not a.controlnets and not sdxl:
-            traffic, traffic_file = recorded_igemm_traffic(L.lib().sr_source_hash().decode())
+        if a.dtype == "f16" and shard is None and not a.controlnets and not sdxl:
+            traffic, traffic_file = recorded_igemm_traffic(L.lib().sr_source_hash().decode(), a.views)
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm family: igemm_kernel / igemm_group_kernel tiles + conv3p_kernel (implicit-GEMM conv/linear, all %d ops of one UNet eval, B=%d)" % (sub.n, (a.views // world if shard is not None else a.views) * 2),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

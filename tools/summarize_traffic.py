@@ -40,5 +40,5 @@ _spec = importlib.util.spec_from_file_location("sr_build", _bp)
 _bm = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_bm)
 res["source_hash"] = _bm.source_hash()
-res["workload"] = "bench.py --roofline-only (sd15-512, 8 views, f16, B=16 UNet evaluation)"
+res["workload"] = sys.argv[2] if len(sys.argv) > 2 else "bench.py --roofline-only (sd15-512, 8 views, f16, B=16 UNet evaluation)"
 print(json.dumps(res, indent=1))
