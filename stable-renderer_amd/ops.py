@@ -246,7 +246,7 @@ def _tune_cold(ar, sig, allow_split, reps):
         ar.tile, ar.split = best
         t0 = min(best_t, timed(3 * reps))
         ar.tile_order = 1
-        if lib.sr_igemm(C.byref(ar), st) == 0 and timed(3 * reps) < 0.97 * t0:
+        if lib.sr_igemm(C.byref(ar), st) == 0 and timed(3 * reps) < float(os.environ.get("SR_TUNE_ORDER_MARGIN", "0.97")) * t0:
             order = 1
         ar.tile_order = 0
     _TUNED[sig] = best + ((1,) if order else ())
