@@ -282,6 +282,25 @@ def sec_sdxl_full():
     print("sdxl_full: %.0f s" % (time.time() - t0))
 
 
+def sec_sdxl_full_128():
+    """the same full-width SDXL base UNet at BASELINE config 5's own latent size: B = 2 (cond + uncond of one view), 128x128 latent
+    (1024^2 frames) -- 12.5 TFLOP through the reference UNetModel on the container's CPU cores"""
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    from stable_renderer_amd.unet import SDXL_CFG
+    attention_basic()
+    t0 = time.time()
+    with torch.no_grad():
+        m, ns, norm = GG.build_unet(SDXL_FULL, seed=8)
+        check_names(ns, unet_names_shapes(SDXL_CFG)[0])
+        x = GG.rnd(31, 2, 4, 128, 128)
+        t = torch.tensor([381.0, 381.0])
+        c = GG.rnd(32, 2, 77, 2048)
+        yv = GG.rnd(33, 2, 2816)
+        y = m(x, t, context=c, y=yv, transformer_options={})
+    GG.save("unet_sdxl_full_128", x=x, t=t, ctx=c, yvec=yv, y=y, seed=np.array(8))
+    print("sdxl_full_128: %.0f s" % (time.time() - t0))
+
+
 SDXL_TINY2 = dict(GG.SDXL_TINY, adm_in_channels=2816)       # the width SDXL.encode_adm produces (pooled 1280 + 6 x 256)
 
 
@@ -362,7 +381,7 @@ def sec_config1_dumps():
     print("config1_dumps: %.0f s" % (time.time() - t0))
 
 
-SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, config4=sec_config4, bench8=sec_bench8, bench8_20=sec_bench8_20, config1_dumps=sec_config1_dumps,
+SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, sdxl_full_128=sec_sdxl_full_128, config4=sec_config4, bench8=sec_bench8, bench8_20=sec_bench8_20, config1_dumps=sec_config1_dumps,
                 config2=sec_config2, config3=sec_config3)
 
 if __name__ == "__main__":
