@@ -262,6 +262,39 @@ def test_config5_multi_object_scene_sdxl_family_overlap_vs_reference():
         assert err < tol * max(1.0, ref.abs().max().item()), (dtype, err, ref.abs().max().item())
 
 
+@pytest.mark.timeout(900)
+def test_config5_at_its_size_full_width_sdxl_1024_vs_reference(monkeypatch):
+    """BASELINE config 5 AT ITS SIZE: the multi-object scene at 1024 x 1024, the FULL-WIDTH SDXL base UNet
+    (2.57 B parameters) behind the reference's model_base.SDXL (encode_adm -> y -> label_emb), OverlapCorresponder (latent overlap on
+    the 128 x 128 latents + K/V injection), 2 views x 3 ddim steps -- against the reference's own sampling run
+    (oracle/gen_golden_full.py config5_1024: 75 TFLOP on the container's CPU cores)"""
+    from stable_renderer_amd import synth
+    from stable_renderer_amd.model_shapes import unet_names_shapes
+    from stable_renderer_amd.pipeline import MultiObjScene
+    from stable_renderer_amd.sampling import encode_adm_sdxl
+    from stable_renderer_amd.unet import SDXL_CFG
+    g = np.load(os.path.join(GOLD, "full_config5_1024.npz"))
+    m = json.loads(bytes(g["meta"]).decode())
+    ns, norms = unet_names_shapes(SDXL_CFG)
+    sd = synth.synth_state_dict(ns, seed=m["unet_seed"], norm_names=norms)
+    S = m["size"]
+    assert S == 1024
+    vec = (encode_adm_sdxl(T(g["pooled_pos"]), width=S, height=S), encode_adm_sdxl(T(g["pooled_neg"]), width=S, height=S))
+    mk = lambda: MultiObjScene(os.path.join(GOLD, "boatlike.obj"), S, S, k=6)
+    ref = T(g["samples"])
+    scale = max(1.0, ref.abs().max().item())
+    for dtype, tol in ((torch.float32, 2e-4), (torch.float16, 2.5e-2)):          # measured 1.2e-5 / 5.8e-3 of max |latent| = 760
+        if dtype == torch.float32:
+            monkeypatch.setenv("SR_AUTOTUNE", "0")               # fp32 at this size: heuristic tiles (timing them would take minutes)
+        else:
+            monkeypatch.delenv("SR_AUTOTUNE", raising=False)
+        s, _, inj = _run(g, mk, dtype, _overlap, unet_cfg=dict(SDXL_CFG), sd_u=sd, vae=False, vector=vec)
+        assert inj == g["inj"].tolist()
+        err = (s - ref).abs().max().item()
+        print(f"config 5 at its size (SDXL full width, 1024^2, 2 views, 3 ddim steps) {dtype}: latent max err {err:.3g} (ref max {scale:.3g})")
+        assert err < tol * scale, (dtype, err, scale)
+
+
 def test_pre_atten_inject_with_two_random_frames_vs_reference():
     """pre_attn_inject_num_of_random_frames = 2: every entry attends to the concatenated tokens of TWO batch entries
     (K/V length 2 x hw, corresponder.py:204-220) -- one UNet forward and one sampling run of the reference's stack"""
