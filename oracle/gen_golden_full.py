@@ -203,23 +203,29 @@ def sec_config2():
 
 
 # ---- BASELINE config 3: mesh through Mesh.Load, 2 overlapped views, 20 steps ------------------------------------------------
-def sec_config3():
+def sec_config3(views=2, name="full_config3"):
     from stable_renderer_amd.pipeline import BoatScene
     attention_basic()
     t0 = time.time()
-    ids, noise, _ = raster_views(BoatScene(os.path.join(GOLD, "boatlike.obj"), 512, 512, k=6, device="cpu"), 2)
+    ids, noise, _ = raster_views(BoatScene(os.path.join(GOLD, "boatlike.obj"), 512, 512, k=6, device="cpu"), views)
     mp, ns, _ = ref_model(GG.SD15, 0)
     s, inj = ref_sample(mp, noise, [[ctx(3), {}]], [[ctx(4), {}]], ids, 20, 8.0, "ddim", "normal", 11,
                         overlap=dict(ratio=0.5, stop=500, n_rand=1))
     img = ref_decode(s)
-    GG.save("full_config3", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, img_sub=sub4(img), inj=np.array(inj),
-            meta=np.frombuffer(json.dumps(dict(views=2, steps=20, sampler="ddim", scheduler="normal", cfg=8.0, rng_seed=11,
+    GG.save(name, noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, img_sub=sub4(img), inj=np.array(inj),
+            meta=np.frombuffer(json.dumps(dict(views=views, steps=20, sampler="ddim", scheduler="normal", cfg=8.0, rng_seed=11,
                                                pos_seed=3, neg_seed=4, unet_seed=0, vae_seed=2, ratio=0.5, stop=500)).encode(), np.uint8))
-    print("config3: %.0f s" % (time.time() - t0))
+    print("%s: %.0f s" % (name, time.time() - t0))
+
+
+def sec_config3_8():
+    """BASELINE configs[2] at its size: the mesh through Mesh.Load, EIGHT overlapped views, 20 ddim steps (B = 16 evaluations through
+    the reference's stack: about half an hour of container CPU, run once)"""
+    sec_config3(views=8, name="full_config3_8")
 
 
 # ---- BASELINE config 4 at real width: SD1.5 UNet + two full-width ControlNets driven by the G-buffers -----------------------
-def sec_config4():
+def sec_config4(views=2, steps=3, name="full_config4", with_plain=True):
     import comfy.cldm.cldm as cldm
     import comfy.controlnet
     import comfy.ops
@@ -229,7 +235,7 @@ def sec_config4():
     from stable_renderer_amd.unet import SD15_CFG
     attention_basic()
     t0 = time.time()
-    ids, noise, nd = raster_views(BakeBallScene(512, 512, k=6, device="cpu"), 2)
+    ids, noise, nd = raster_views(BakeBallScene(512, 512, k=6, device="cpu"), views)
     ndf = torch.from_numpy(nd.view(np.float16)).float()                          # (N,H,W,4): rgb = normal, a = depth
     hints = {"depth": ndf[..., 3:4].expand(-1, -1, -1, 3).contiguous(), "normal": ndf[..., :3].contiguous()}
     mp, ns, _ = ref_model(GG.SD15, 0)
@@ -242,16 +248,22 @@ def sec_config4():
         check_names(cns, controlnet_names_shapes(SD15_CFG)[0])
         wrapped = comfy.controlnet.ControlNet(cn, load_device=torch.device("cpu"))
         pos = ref_nodes.ControlNetApply().apply_controlnet(pos, wrapped, hints[plane], strength)[0]
-    s, _ = ref_sample(mp, noise, pos, neg, None, 3, 8.0, "euler", "normal", 21)
+    s, _ = ref_sample(mp, noise, pos, neg, None, steps, 8.0, "euler", "normal", 21)
     # the same run without the ControlNets: the test also checks that the nets move the result
-    s_plain, _ = ref_sample(mp, noise, [[ctx(5), {}]], [[ctx(6), {}]], None, 3, 8.0, "euler", "normal", 21)
+    s_plain = ref_sample(mp, noise, [[ctx(5), {}]], [[ctx(6), {}]], None, steps, 8.0, "euler", "normal", 21)[0] if with_plain else s[:0]
     img = ref_decode(s)
-    GG.save("full_config4", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), nd_sha=np.frombuffer(sha(nd).encode(), np.uint8),
+    GG.save(name, noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), nd_sha=np.frombuffer(sha(nd).encode(), np.uint8),
             samples=s, samples_plain=s_plain, img_sub=sub4(img),
-            meta=np.frombuffer(json.dumps(dict(views=2, steps=3, sampler="euler", scheduler="normal", cfg=8.0, rng_seed=21, pos_seed=5,
+            meta=np.frombuffer(json.dumps(dict(views=views, steps=steps, sampler="euler", scheduler="normal", cfg=8.0, rng_seed=21, pos_seed=5,
                                                neg_seed=6, unet_seed=0, vae_seed=2, cn_seeds=[20, 21], planes=["depth", "normal"],
                                                strengths=[1.0, 0.7])).encode(), np.uint8))
-    print("config4: %.0f s" % (time.time() - t0))
+    print("%s: %.0f s" % (name, time.time() - t0))
+
+
+def sec_config4_3x20():
+    """BASELINE configs[3]'s per-GPU share at its length: THREE frames (B = 6) x 20 steps with the two full-width G-buffer-driven
+    ControlNets through the reference's comfy.controlnet + ControlNetApply (about a quarter of an hour of container CPU)"""
+    sec_config4(views=3, steps=20, name="full_config4_3x20", with_plain=False)
 
 
 # ---- BASELINE config 5 ---------------------------------------------------------------------------------------------------------
@@ -406,10 +418,10 @@ def sec_config1_dumps():
 
 
 SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, sdxl_full_128=sec_sdxl_full_128, config5_1024=sec_config5_1024, config4=sec_config4, bench8=sec_bench8, bench8_20=sec_bench8_20, config1_dumps=sec_config1_dumps,
-                config2=sec_config2, config3=sec_config3)
+                config2=sec_config2, config3=sec_config3, config3_8=sec_config3_8, config4_3x20=sec_config4_3x20)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for s_ in (_ARGV or [k for k in SECTIONS if k not in ("bench8_20", "config5_1024")]):
+    for s_ in (_ARGV or [k for k in SECTIONS if k not in ("bench8_20", "config5_1024", "config3_8", "config4_3x20")]):
         print("==", s_, flush=True)
         SECTIONS[s_]()

@@ -110,7 +110,7 @@ def _run(gold, make_scene, dtype, corresponder_fn, controls=None, unet_cfg=None,
 
 # fp16 floors = what the GPU runs measure minus 6 dB (fp16 is the dtype of every bench number: a kernel change that costs more than
 # that fails here); fp32: the north_star's 40 dB and a latent relative error of 1e-3 (measured 1.2e-5 .. 6e-5)
-FLOOR16 = {"bench8": 50.0, "bench8_20": 54.0, "config2": 54.0, "config3": 49.0, "config4": 50.0}
+FLOOR16 = {"bench8": 50.0, "bench8_20": 54.0, "config2": 54.0, "config3": 49.0, "config4": 50.0, "config3_8": 40.0, "config4_3x20": 54.0}
 
 
 def _check(tag, gold, r32, r16, fp16_floor, rel32_max=1e-3):
@@ -177,6 +177,20 @@ def test_config3_boat_mesh_two_overlapped_views_512_20_steps_vs_reference():
 
 
 @pytest.mark.timeout(900)
+def test_config3_at_its_size_boat_mesh_eight_overlapped_views_20_steps_vs_reference():
+    """BASELINE configs[2] at its size: the mesh through Mesh.Load, EIGHT views with latent overlap + K/V injection, 20 ddim steps
+    (B = 16 evaluations) against the reference's own run (oracle/gen_golden_full.py config3_8)"""
+    from stable_renderer_amd.pipeline import BoatScene
+    g = np.load(os.path.join(GOLD, "full_config3_8.npz"))
+    assert json.loads(bytes(g["meta"]).decode())["views"] == 8
+    mk = lambda: BoatScene(os.path.join(GOLD, "boatlike.obj"), 512, 512, k=6)
+    r32 = _run(g, mk, torch.float32, _overlap)
+    r16 = _run(g, mk, torch.float16, _overlap)
+    assert r32[2] == g["inj"].tolist() and r16[2] == g["inj"].tolist()
+    _check("config 3 at its size (boat-like mesh, 512^2, 20 steps, 8 overlapped views, ddim/normal cfg 8)", g, r32, r16, FLOOR16["config3_8"])
+
+
+@pytest.mark.timeout(900)
 def test_config4_two_full_width_controlnets_512_vs_reference():
     """comfy/controlnet.py:180-214 + cldm.ControlNet at SD1.5 width (361 M parameters each), hints = the depth and normal planes
     of the same views, strengths 1.0 / 0.7, chained as ControlNetApply chains them (control_merge)"""
@@ -199,6 +213,31 @@ def test_config4_two_full_width_controlnets_512_vs_reference():
     _check("config 4 (SD1.5 UNet + 2 full-width ControlNets, 512^2, 2 views, euler/normal cfg 8, 3 steps)", g, r32, r16, FLOOR16["config4"])
     plain = T(g["samples_plain"])                                # the reference's run WITHOUT the nets: they must matter
     assert (T(g["samples"]) - plain).abs().max() > 50 * (r32[0] - T(g["samples"])).abs().max()
+
+
+@pytest.mark.timeout(900)
+def test_config4_at_its_length_three_frames_twenty_steps_two_controlnets_vs_reference():
+    """BASELINE configs[3]'s per-GPU share at its length: THREE frames per GPU (B = 6) x 20 euler steps with the two full-width
+    G-buffer-driven ControlNets, against the reference's comfy.controlnet + ControlNetApply run (gen_golden_full.py config4_3x20)"""
+    from stable_renderer_amd import synth
+    from stable_renderer_amd.controlnet import ControlNet
+    from stable_renderer_amd.corresponder import DefaultCorresponder
+    from stable_renderer_amd.model_shapes import controlnet_names_shapes
+    from stable_renderer_amd.pipeline import BakeBallScene
+    from stable_renderer_amd.unet import SD15_CFG
+    g = np.load(os.path.join(GOLD, "full_config4_3x20.npz"))
+    m = json.loads(bytes(g["meta"]).decode())
+    assert (m["views"], m["steps"]) == (3, 20)
+    cns, cnorms = controlnet_names_shapes(SD15_CFG)
+    mk = lambda: BakeBallScene(512, 512, k=6)
+
+    def controls(dtype):
+        return [(pl, ControlNet(synth.synth_state_dict(cns, seed=s, norm_names=cnorms), SD15_CFG, dtype=dtype, strength=st))
+                for pl, s, st in zip(m["planes"], m["cn_seeds"], m["strengths"])]
+    r32 = _run(g, mk, torch.float32, DefaultCorresponder, controls=controls(torch.float32), planes_sha=bytes(g["nd_sha"]).decode())
+    r16 = _run(g, mk, torch.float16, DefaultCorresponder, controls=controls(torch.float16))
+    _check("config 4 at its length (SD1.5 UNet + 2 full-width ControlNets, 512^2, 3 frames, euler/normal cfg 8, 20 steps)", g, r32, r16,
+           FLOOR16["config4_3x20"])
 
 
 @pytest.mark.timeout(900)
