@@ -110,7 +110,7 @@ def _run(gold, make_scene, dtype, corresponder_fn, controls=None, unet_cfg=None,
 
 # fp16 floors = what the GPU runs measure minus 6 dB (fp16 is the dtype of every bench number: a kernel change that costs more than
 # that fails here); fp32: the north_star's 40 dB and a latent relative error of 1e-3 (measured 1.2e-5 .. 6e-5)
-FLOOR16 = {"bench8": 50.0, "bench8_20": 54.0, "config2": 54.0, "config3": 49.0, "config4": 50.0, "config3_8": 40.0, "config4_3x20": 54.0}
+FLOOR16 = {"bench8": 50.0, "bench8_20": 54.0, "config2": 54.0, "config3": 49.0, "config4": 50.0, "config3_8": 50.0, "config4_3x20": 54.0}
 
 
 def _check(tag, gold, r32, r16, fp16_floor, rel32_max=1e-3):
