@@ -335,7 +335,7 @@ def sec_config5():
     print("config5: %.0f s" % (time.time() - t0))
 
 
-def sec_config5_1024():
+def sec_config5_1024(views=2, steps=3, name="full_config5_1024", rng_seed=57):
     """BASELINE config 5 AT ITS SIZE: the multi-object scene at 1024^2 through the reference's SDXL model class with the FULL-WIDTH
     SDXL base UNet (2.57 B parameters; encode_adm -> y -> label_emb) and OverlapCorresponder (latent overlap + K/V injection):
     2 views, 3 ddim steps = 12 sample-evaluations of 6.3 TFLOP on the container's CPU cores"""
@@ -344,19 +344,25 @@ def sec_config5_1024():
     from stable_renderer_amd.unet import SDXL_CFG
     attention_basic()
     t0 = time.time()
-    ids, noise, _ = raster_views(MultiObjScene(os.path.join(GOLD, "boatlike.obj"), 1024, 1024, k=6, device="cpu"), 2)
+    ids, noise, _ = raster_views(MultiObjScene(os.path.join(GOLD, "boatlike.obj"), 1024, 1024, k=6, device="cpu"), views)
     print("  raster %.0f s" % (time.time() - t0), flush=True)
     mp, ns, norm = ref_model(SDXL_FULL, 8, family="sdxl")
     check_names(ns, unet_names_shapes(SDXL_CFG)[0])
     print("  model %.0f s" % (time.time() - t0), flush=True)
     pp, pn = GG.rnd(41, 1, 1280), GG.rnd(42, 1, 1280)
     pos, neg = [[ctx(43, 2048), {"pooled_output": pp}]], [[ctx(44, 2048), {"pooled_output": pn}]]
-    s, inj = ref_sample(mp, noise, pos, neg, ids, 3, 6.0, "ddim", "normal", 57, overlap=dict(ratio=0.5, stop=500, n_rand=1))
-    GG.save("full_config5_1024", noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, inj=np.array(inj),
+    s, inj = ref_sample(mp, noise, pos, neg, ids, steps, 6.0, "ddim", "normal", rng_seed, overlap=dict(ratio=0.5, stop=500, n_rand=1))
+    GG.save(name, noise=noise, ids_sha=np.frombuffer(sha(ids).encode(), np.uint8), samples=s, inj=np.array(inj),
             pooled_pos=pp, pooled_neg=pn,
-            meta=np.frombuffer(json.dumps(dict(views=2, steps=3, sampler="ddim", scheduler="normal", cfg=6.0, rng_seed=57, pos_seed=43,
+            meta=np.frombuffer(json.dumps(dict(views=views, steps=steps, sampler="ddim", scheduler="normal", cfg=6.0, rng_seed=rng_seed, pos_seed=43,
                                                neg_seed=44, unet_seed=8, ratio=0.5, stop=500, size=1024)).encode(), np.uint8))
-    print("config5_1024: %.0f s" % (time.time() - t0))
+    print("%s: %.0f s" % (name, time.time() - t0))
+
+
+def sec_config5_1024_1x20():
+    """config 5's per-GPU share at its length: ONE view (B = 2) x 20 ddim steps of the full-width SDXL UNet at 1024^2 (40 sample-
+    evaluations of 6.3 TFLOP: about 40 minutes of container CPU)"""
+    sec_config5_1024(views=1, steps=20, name="full_config5_1024_1x20", rng_seed=58)
 
 
 # ---- pre_atten_inject with TWO random frames (K/V length 2 x hw, corresponder.py:204-220) --------------------------------------
@@ -417,11 +423,11 @@ def sec_config1_dumps():
     print("config1_dumps: %.0f s" % (time.time() - t0))
 
 
-SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, sdxl_full_128=sec_sdxl_full_128, config5_1024=sec_config5_1024, config4=sec_config4, bench8=sec_bench8, bench8_20=sec_bench8_20, config1_dumps=sec_config1_dumps,
+SECTIONS = dict(nrand2=sec_nrand2, config5=sec_config5, sdxl_full=sec_sdxl_full, sdxl_full_128=sec_sdxl_full_128, config5_1024=sec_config5_1024, config5_1024_1x20=sec_config5_1024_1x20, config4=sec_config4, bench8=sec_bench8, bench8_20=sec_bench8_20, config1_dumps=sec_config1_dumps,
                 config2=sec_config2, config3=sec_config3, config3_8=sec_config3_8, config4_3x20=sec_config4_3x20)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for s_ in (_ARGV or [k for k in SECTIONS if k not in ("bench8_20", "config5_1024", "config3_8", "config4_3x20")]):
+    for s_ in (_ARGV or [k for k in SECTIONS if k not in ("bench8_20", "config5_1024", "config5_1024_1x20", "config3_8", "config4_3x20")]):
         print("==", s_, flush=True)
         SECTIONS[s_]()
